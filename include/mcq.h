@@ -1,0 +1,153 @@
+/*
+ * mcq.h -- C-ABI of the MI355X-native Metropolis sweep for the 3D N^2-queens problem.
+ *
+ * The reference (galgantar/monte-carlo-collective) has no FFI or plugin interface: its
+ * seam is the Python function run_experiment() (experiments.py:475-573), which fans one
+ * task per chain out to a process pool (experiments.py:507-517) and each task runs
+ * metropolis_mcmc_board (experiments.py:282-376) or metropolis_mcmc
+ * (experiments.py:199-279).  This header is the boundary a maintainer of the reference
+ * would bind with ctypes to replace that fan-out + sweep: one call runs ALL chains.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; the library never returns owned memory.
+ *   - every function returns 0 on success, a negative MCQ_E* code on error; the message
+ *     for the last error of the calling thread is mcq_last_error().
+ *   - no exceptions cross the boundary; the Python side maps MCQ_EINVAL to ValueError
+ *     (the reference raises ValueError for unknown schedule / init modes:
+ *     experiments.py:105, mcmc.py:104, mcmc_board.py:59) and the rest to RuntimeError.
+ *
+ * Two libraries export (subsets of) this interface:
+ *   libmcq_hip.so     the product: hand-written HIP kernels for gfx950 (csrc/).
+ *   libmcq_oracle.so  TEST INFRASTRUCTURE ONLY: a plain-C CPU restatement of the
+ *                     reference algorithm (oracle/), exporting mcq_oracle_run().
+ */
+#ifndef MCQ_H
+#define MCQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCQ_ABI_VERSION 1
+
+/* error codes */
+#define MCQ_OK 0
+#define MCQ_EINVAL (-1)   /* bad parameter (-> ValueError) */
+#define MCQ_EDEVICE (-2)  /* HIP runtime error, no device, launch failure */
+#define MCQ_ENOMEM (-3)   /* workspace too small / allocation failure */
+
+/* mcmc_type: experiments.py:497-502 ("board" -> board chain, anything else -> full_3d) */
+#define MCQ_MODE_BOARD 0
+#define MCQ_MODE_FULL3D 1
+
+/* init_mode: mcmc_board.py:26-59, mcmc.py:20-104 */
+#define MCQ_INIT_RANDOM 0
+#define MCQ_INIT_LATIN 1
+#define MCQ_INIT_KLARNER 2
+
+/* betta_scheduling.type: experiments.py:79-105 */
+#define MCQ_SCHED_CONSTANT 0
+#define MCQ_SCHED_LINEAR 1
+#define MCQ_SCHED_EXPONENTIAL 2
+#define MCQ_SCHED_LOGARITHMIC 3
+#define MCQ_SCHED_SINUSOIDAL 4
+
+/* random stream */
+#define MCQ_RNG_MT19937_NUMPY 0 /* NumPy legacy global RandomState: bit-parity with the reference */
+
+/* energy_history trace */
+#define MCQ_TRACE_NONE 0 /* only per-chain summaries (measure_min_energy_vs_N discards histories: experiments.py:1061) */
+#define MCQ_TRACE_I32 1  /* full int32 trace + accept bits (experiments.py:355, 329-332) */
+
+/* flags */
+#define MCQ_FLAG_EXACT_EXP 1u /* evaluate exp(-beta*dE) in float64 on every step (disable the bracketing pre-filter) */
+
+/* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319). */
+#define MCQ_MIN_N 2
+#define MCQ_MAX_N 32
+
+typedef struct mcq_params {
+    int32_t abi_version;     /* MCQ_ABI_VERSION */
+    int32_t N;               /* board edge; Q = N*N queens */
+    int32_t mode;            /* MCQ_MODE_* */
+    int32_t init;            /* MCQ_INIT_* */
+    int32_t sched;           /* MCQ_SCHED_* */
+    int32_t rng;             /* MCQ_RNG_* */
+    int32_t trace;           /* MCQ_TRACE_* */
+    uint32_t flags;          /* MCQ_FLAG_* */
+    double beta_const;       /* constant schedule            (experiments.py:13-16)  */
+    double beta_start;       /* annealing schedules          (experiments.py:19-77)  */
+    double beta_end;
+    int64_t n_steps;         /* steps per chain = schedule length                    */
+    int64_t n_chains;        /* n_runs; chain r is seeded with seeds[r] (= base_seed + r, experiments.py:508) */
+    int64_t patience;        /* early_stop_patience, board only (experiments.py:349-353); < 0 = None */
+    int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1 */
+    int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
+    int32_t lanes_per_chain; /* HIP only: 16, 32 or 64 lanes of a wavefront per chain; 0 = library default */
+    int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
+} mcq_params;
+
+/*
+ * Per-chain outputs; every array is caller-allocated.  state_bytes = mcq_state_bytes(N, mode):
+ *   board:   N*N uint8 heights, row-major heights[i][j]        (mcmc_board.py:28)
+ *   full_3d: Q*3 uint8 (i, j, k) per queen, in queen-index order (mcmc.py:101)
+ * Pointers that may be NULL are marked optional.
+ */
+typedef struct mcq_outputs {
+    int32_t* energy_hist;    /* optional unless trace == I32: [n_chains][hist_stride]; entry 0 = E0, entry s+1 = energy after step s */
+    uint64_t* accept_bits;   /* optional unless trace == I32: [n_chains][bits_stride]; bit (s & 63) of word s >> 6 = step s accepted */
+    int64_t* hist_len;       /* [n_chains] entries of energy_hist that are valid (n_steps + 1, fewer after an early stop) */
+    int64_t* steps_executed; /* [n_chains] proposals made (hist_len - 1, +1 when the chain broke out early) */
+    int32_t* initial_energy; /* [n_chains] E0 */
+    int32_t* best_energy;    /* [n_chains] */
+    int32_t* final_energy;   /* [n_chains] */
+    int64_t* steps_to_best;  /* [n_chains] first index of min(energy_history) (experiments.py:364-365) */
+    int64_t* n_accepted;     /* [n_chains] */
+    int64_t* near_ties;      /* optional [n_chains]: steps whose uniform fell within 4 ulp of the acceptance probability */
+    uint8_t* best_state;     /* optional [n_chains][state_bytes] */
+    uint8_t* final_state;    /* optional [n_chains][state_bytes] */
+} mcq_outputs;
+
+/* ---- exported by libmcq_hip.so ------------------------------------------------------------ */
+
+int mcq_abi_version(void);
+const char* mcq_last_error(void);
+int mcq_device_count(void);
+
+/* bytes of one chain's state record in best_state / final_state; 0 on bad arguments */
+size_t mcq_state_bytes(int32_t N, int32_t mode);
+
+/* bytes of device scratch mcq_run_device needs for these parameters; 0 on bad arguments */
+size_t mcq_workspace_bytes(const mcq_params* p);
+
+/*
+ * Replaces run_experiment's fan-out + per-chain sweep (experiments.py:507-546) with
+ * device-resident buffers.  `seeds` (uint32[n_chains]) and every non-NULL pointer of
+ * `out` are DEVICE pointers; `workspace` is a device buffer of at least
+ * mcq_workspace_bytes(p) bytes.  Work is enqueued on `hip_stream` (a hipStream_t, NULL =
+ * the default stream) and the call returns without synchronising.
+ */
+int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out,
+                   void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
+ * Same computation with HOST buffers: allocates device memory, uploads seeds, runs,
+ * downloads every non-NULL output and frees.  Blocking.  `kernel_seconds` (optional)
+ * receives the device time of init + sweep measured with HIP events.
+ */
+int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out,
+                 double* kernel_seconds);
+
+/* ---- exported by libmcq_oracle.so (tests / smoke / cpu_baseline only) --------------------- */
+
+/* CPU restatement of the reference; host buffers; n_threads <= 1 runs chains in the calling thread. */
+int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads);
+const char* mcq_oracle_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCQ_H */

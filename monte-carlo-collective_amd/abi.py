@@ -1,0 +1,185 @@
+"""ctypes mirror of include/mcq.h (the C-ABI under run_experiment).
+
+Everything here is plain data: the structs, the enum values, and the mapping from the
+reference's string vocabulary (`mcmc_type`, `init_mode`, `betta_scheduling.type`;
+experiments.py:79-105, 497-502; mcmc_board.py:26-59) to those enums.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+
+OK, EINVAL, EDEVICE, ENOMEM = 0, -1, -2, -3
+
+MODE_BOARD, MODE_FULL3D = 0, 1
+INIT = {"random": 0, "latin": 1, "klarner": 2}
+SCHED = {
+    "constant": 0,
+    "linear_annealing": 1,
+    "exponential_annealing": 2,
+    "logarithmic_annealing": 3,
+    "sinusoidal_annealing": 4,
+}
+RNG_MT19937_NUMPY = 0
+TRACE_NONE, TRACE_I32 = 0, 1
+FLAG_EXACT_EXP = 1
+
+MIN_N, MAX_N = 2, 32
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("N", C.c_int32),
+        ("mode", C.c_int32),
+        ("init", C.c_int32),
+        ("sched", C.c_int32),
+        ("rng", C.c_int32),
+        ("trace", C.c_int32),
+        ("flags", C.c_uint32),
+        ("beta_const", C.c_double),
+        ("beta_start", C.c_double),
+        ("beta_end", C.c_double),
+        ("n_steps", C.c_int64),
+        ("n_chains", C.c_int64),
+        ("patience", C.c_int64),
+        ("hist_stride", C.c_int64),
+        ("bits_stride", C.c_int64),
+        ("lanes_per_chain", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class Outputs(C.Structure):
+    _fields_ = [
+        ("energy_hist", C.c_void_p),
+        ("accept_bits", C.c_void_p),
+        ("hist_len", C.c_void_p),
+        ("steps_executed", C.c_void_p),
+        ("initial_energy", C.c_void_p),
+        ("best_energy", C.c_void_p),
+        ("final_energy", C.c_void_p),
+        ("steps_to_best", C.c_void_p),
+        ("n_accepted", C.c_void_p),
+        ("near_ties", C.c_void_p),
+        ("best_state", C.c_void_p),
+        ("final_state", C.c_void_p),
+    ]
+
+
+# field -> (dtype, per-chain shape builder)
+OUTPUT_DTYPES = {
+    "energy_hist": np.int32,
+    "accept_bits": np.uint64,
+    "hist_len": np.int64,
+    "steps_executed": np.int64,
+    "initial_energy": np.int32,
+    "best_energy": np.int32,
+    "final_energy": np.int32,
+    "steps_to_best": np.int64,
+    "n_accepted": np.int64,
+    "near_ties": np.int64,
+    "best_state": np.uint8,
+    "final_state": np.uint8,
+}
+
+
+def state_bytes(N, mode):
+    """Bytes of one chain's state record: N*N heights (board) or Q*3 coordinates (full_3d)."""
+    return N * N if mode == MODE_BOARD else 3 * N * N
+
+
+def hist_stride_for(n_steps):
+    """Row stride of energy_hist: n_steps + 1 entries rounded up to 64 (256-byte rows, so every
+    64-entry block a wavefront flushes is one aligned 256-byte store)."""
+    return ((n_steps + 1 + 63) // 64) * 64
+
+
+def bits_stride_for(n_steps):
+    return max(1, (n_steps + 63) // 64)
+
+
+def output_shapes(p, trace=True, states=True):
+    """name -> shape for the arrays a call with parameters `p` fills."""
+    n = p.n_chains
+    shapes = {k: (n,) for k in ("hist_len", "steps_executed", "initial_energy", "best_energy", "final_energy",
+                                "steps_to_best", "n_accepted", "near_ties")}
+    if trace:
+        shapes["energy_hist"] = (n, p.hist_stride)
+        shapes["accept_bits"] = (n, p.bits_stride)
+    if states:
+        sb = state_bytes(p.N, p.mode)
+        shapes["best_state"] = (n, sb)
+        shapes["final_state"] = (n, sb)
+    return shapes
+
+
+def mode_of(mcmc_type):
+    """experiments.py:497-502: "board" selects the board chain, anything else the full_3d chain."""
+    return MODE_BOARD if mcmc_type == "board" else MODE_FULL3D
+
+
+def normalise_patience(early_stop_patience):
+    """experiments.py:284-285: None, 'None' and 'null' all disable early stopping."""
+    if early_stop_patience in (None, "None", "null"):
+        return -1
+    v = int(early_stop_patience)
+    return v if v >= 0 else 0  # a negative patience stops at the first step, like 0
+
+
+def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="full_3d", early_stop_patience=None,
+                trace=True, flags=0, lanes_per_chain=0, device=-1):
+    """Build a Params from the reference's vocabulary.  Raises ValueError exactly where the
+    reference does: unknown schedule type (experiments.py:105), missing beta parameters
+    (experiments.py:85-102), unknown init_mode (mcmc_board.py:59, mcmc.py:104)."""
+    if schedule_params is None:
+        raise ValueError("schedule_params is required")
+    st = schedule_params.get("type")
+    if st not in SCHED:
+        raise ValueError(f"Unknown betta_scheduling type: {st}")
+    bc = schedule_params.get("beta_const")
+    bs = schedule_params.get("beta_start")
+    be = schedule_params.get("beta_end")
+    if st == "constant":
+        if bc is None:
+            raise ValueError("beta_const required for constant schedule")
+    elif bs is None or be is None:
+        raise ValueError(f"beta_start and beta_end required for {st} schedule")
+    if init_mode not in INIT:
+        raise ValueError(f"Unknown init_mode: {init_mode}")
+    N = int(N)
+    if not (MIN_N <= N <= MAX_N):
+        raise ValueError(f"N must be in [{MIN_N}, {MAX_N}], got {N}")
+    n_steps = int(n_steps)
+    if n_steps < 0:
+        raise ValueError("n_steps must be >= 0")
+    p = Params()
+    p.abi_version = ABI_VERSION
+    p.N = N
+    p.mode = mode_of(mcmc_type)
+    p.init = INIT[init_mode]
+    p.sched = SCHED[st]
+    p.rng = RNG_MT19937_NUMPY
+    p.trace = TRACE_I32 if trace else TRACE_NONE
+    p.flags = flags
+    p.beta_const = float(bc) if bc is not None else 0.0
+    p.beta_start = float(bs) if bs is not None else 0.0
+    p.beta_end = float(be) if be is not None else 0.0
+    p.n_steps = n_steps
+    p.n_chains = int(n_chains)
+    p.patience = normalise_patience(early_stop_patience) if p.mode == MODE_BOARD else -1
+    p.hist_stride = hist_stride_for(n_steps)
+    p.bits_stride = bits_stride_for(n_steps)
+    p.lanes_per_chain = lanes_per_chain
+    p.device = device
+    return p
+
+
+def seeds_for(base_seed, n_chains):
+    """Chain r is seeded with base_seed + r (experiments.py:508); NumPy's legacy seed() accepts
+    only 0 <= seed <= 2**32 - 1 and raises ValueError otherwise."""
+    s = np.arange(n_chains, dtype=np.int64) + int(base_seed)
+    if n_chains and (s[0] < 0 or s[-1] > 2**32 - 1):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    return s.astype(np.uint32)

@@ -1,0 +1,588 @@
+/*
+ * mcq_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's per-chain Metropolis sweep
+ * (galgantar/monte-carlo-collective: experiments.py, mcmc.py, mcmc_board.py).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * shipped path (libmcq_hip.so) never links or calls it.
+ *
+ * It follows the reference's OWN algorithm (O(N^2) scan of every queen with the
+ * reference's six / seven attack predicates, O(Q^2) pairwise initial energy), not the
+ * GPU kernels' neighbour-scan formulation, so that the two are independent derivations.
+ *
+ * Parity is PINNED: tests/golden/ holds vectors produced by importing the reference
+ * itself (tools/gen_golden.py) and tests/test_oracle_golden.py checks this file against
+ * all of them.  The random stream is NumPy's legacy global RandomState (MT19937), a
+ * third-party dependency of the reference (requirements.txt:1, unpinned; NumPy 2.2.6 in
+ * the build container); its published algorithm is restated below and checked against
+ * NumPy itself in tests/test_oracle_rng.py.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -shared -fPIC).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/mcq.h"
+
+static __thread char g_err[256];
+
+const char* mcq_oracle_last_error(void) { return g_err; }
+
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NumPy legacy RandomState (MT19937).  Call sites in the reference: experiments.py:201,
+ * 221, 227-229, 239, 288, 311-312, 317-319, 327; mcmc_board.py:28, 57; mcmc.py:82-84, 97.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t key[624];
+    int pos;
+} mt_t;
+
+/* np.random.seed(int): Knuth's linear recurrence, pos = 624 so the first draw twists. */
+static void mt_seed(mt_t* s, uint32_t seed) {
+    for (int p = 0; p < 624; p++) {
+        s->key[p] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)p + 1u;
+    }
+    s->pos = 624;
+}
+
+static void mt_twist(mt_t* s) {
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MAT = 0x9908b0dfu;
+    uint32_t* k = s->key;
+    int i;
+    for (i = 0; i < 624 - 397; i++) {
+        uint32_t y = (k[i] & UP) | (k[i + 1] & LO);
+        k[i] = k[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+    }
+    for (; i < 623; i++) {
+        uint32_t y = (k[i] & UP) | (k[i + 1] & LO);
+        k[i] = k[i + 397 - 624] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+    }
+    uint32_t y = (k[623] & UP) | (k[0] & LO);
+    k[623] = k[396] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+    s->pos = 0;
+}
+
+static uint32_t mt_u32(mt_t* s) {
+    if (s->pos == 624) mt_twist(s);
+    uint32_t y = s->key[s->pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* Masked rejection on 32-bit words, as RandomState.randint(0, m+1) and shuffle use for
+ * ranges below 2^32: m == 0 consumes nothing. */
+static uint32_t mt_bounded(mt_t* s, uint32_t m) {
+    if (m == 0) return 0;
+    uint32_t mask = m;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    do {
+        v = mt_u32(s) & mask;
+    } while (v > m);
+    return v;
+}
+
+/* np.random.random(): 53-bit double from two words, high part first. */
+static double mt_double(mt_t* s) {
+    uint32_t a = mt_u32(s) >> 5, b = mt_u32(s) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+/* exported for tests/test_oracle_rng.py: kind 0 = raw u32, 1 = bounded(arg), 2 = double */
+int mcq_oracle_rng_stream(uint32_t seed, int kind, uint32_t arg, int64_t n, uint32_t* out_u32,
+                          double* out_f64) {
+    mt_t s;
+    mt_seed(&s, seed);
+    for (int64_t t = 0; t < n; t++) {
+        if (kind == 0) out_u32[t] = mt_u32(&s);
+        else if (kind == 1) out_u32[t] = mt_bounded(&s, arg);
+        else out_f64[t] = mt_double(&s);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * beta schedules, experiments.py:13-77.  Each expression keeps the reference's evaluation
+ * order; the file is compiled with -ffp-contract=off so no product-sum is fused.
+ * ---------------------------------------------------------------------------------------- */
+static double beta_at(const mcq_params* p, int64_t step) {
+    const double bs = p->beta_start, be = p->beta_end;
+    const int64_t n = p->n_steps;
+    switch (p->sched) {
+    case MCQ_SCHED_CONSTANT: /* experiments.py:13-16 */
+        return p->beta_const;
+    case MCQ_SCHED_LINEAR: { /* experiments.py:19-25 */
+        if (n <= 1) return be;
+        double frac = (double)step / (double)(n - 1);
+        return bs + frac * (be - bs);
+    }
+    case MCQ_SCHED_EXPONENTIAL: { /* experiments.py:27-40 */
+        if (n <= 1) return be;
+        double log_ratio = log(be / bs);
+        int64_t c = step < 0 ? 0 : (step > n - 1 ? n - 1 : step);
+        double t = (double)c / (double)(n - 1);
+        return bs * exp(log_ratio * t);
+    }
+    case MCQ_SCHED_LOGARITHMIC: { /* experiments.py:42-58 */
+        if (n <= 1) return be;
+        double log_norm = log((double)(1 + n));
+        int64_t c = step < 0 ? 0 : (step > n ? n : step);
+        return bs + (be - bs) * (log((double)(1 + c)) / log_norm);
+    }
+    default: { /* sinusoidal, experiments.py:60-77 */
+        if (n <= 1) return be;
+        int64_t c = step < 0 ? 0 : (step > n ? n : step);
+        double x = 3.141592653589793 * (double)c / (double)n;
+        return bs + (be - bs) * (1.0 - cos(x)) / 2.0;
+    }
+    }
+}
+
+int mcq_oracle_beta_table(const mcq_params* p, const int64_t* steps, int64_t n, double* out) {
+    for (int64_t t = 0; t < n; t++) out[t] = beta_at(p, steps[t]);
+    return 0;
+}
+
+static int gcd_int(int a, int b) {
+    while (b) {
+        int t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+/* largest m < N with gcd(m, 210) == 1 (mcmc_board.py:38-42, mcmc.py:46-50); 0 if none */
+static int klarner_core(int N) {
+    for (int m = N - 1; m > 0; m--)
+        if (gcd_int(m, 210) == 1) return m;
+    return 0;
+}
+
+static int iabs(int v) { return v < 0 ? -v : v; }
+
+/* ------------------------------------------------------------------------------------------
+ * Board chain: State3DQueensBoard (mcmc_board.py) + metropolis_mcmc_board (experiments.py:282-376)
+ * ---------------------------------------------------------------------------------------- */
+static int board_init(int N, int init, mt_t* rng, int* h) {
+    if (init == MCQ_INIT_RANDOM) { /* mcmc_board.py:28: N*N bounded draws, row-major */
+        for (int c = 0; c < N * N; c++) h[c] = (int)mt_bounded(rng, (uint32_t)(N - 1));
+    } else if (init == MCQ_INIT_LATIN) { /* mcmc_board.py:30-31 */
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) h[i * N + j] = (i + j) % N;
+    } else if (init == MCQ_INIT_KLARNER) { /* mcmc_board.py:33-57 */
+        if (gcd_int(N, 210) == 1) {
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++) h[i * N + j] = (3 * i + 5 * j) % N;
+        } else {
+            int M = klarner_core(N);
+            if (M == 0) return -1;
+            memset(h, 0, sizeof(int) * (size_t)(N * N));
+            for (int i = 0; i < M; i++)
+                for (int j = 0; j < M; j++) h[i * N + j] = (3 * i + 5 * j) % M;
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++)
+                    if (!(i < M && j < M)) h[i * N + j] = (int)mt_bounded(rng, (uint32_t)(N - 1));
+        }
+    } else {
+        return -1;
+    }
+    return 0;
+}
+
+/* the six predicates of mcmc_board.py:103-119 / 177-191 */
+static int board_attacks(int i, int j, int k, int i2, int j2, int k2) {
+    int di = iabs(i2 - i), dj = iabs(j2 - j), dk = iabs(k2 - k);
+    int same_ik = (i2 == i) && (k2 == k);
+    int same_jk = (j2 == j) && (k2 == k);
+    int plane_k = (k2 == k) && (di == dj);
+    int plane_j = (j2 == j) && (di == dk);
+    int plane_i = (i2 == i) && (dj == dk);
+    int space = (di == dj) && (dj == dk);
+    return same_ik | same_jk | plane_k | plane_j | plane_i | space;
+}
+
+/* mcmc_board.py:82-122 */
+static int board_energy(int N, const int* h) {
+    if (N < 2) return 0;
+    int Q = N * N, e = 0;
+    for (int a = 0; a < Q; a++)
+        for (int b = a + 1; b < Q; b++)
+            e += board_attacks(a / N, a % N, h[a], b / N, b % N, h[b]);
+    return e;
+}
+
+/* mcmc_board.py:147-193: every column except (i, j) itself */
+static int board_conflicts(int N, const int* h, int i, int j, int k) {
+    int c = 0;
+    for (int i2 = 0; i2 < N; i2++)
+        for (int j2 = 0; j2 < N; j2++) {
+            if (i2 == i && j2 == j) continue;
+            c += board_attacks(i, j, k, i2, j2, h[i2 * N + j2]);
+        }
+    return c;
+}
+
+typedef struct {
+    const mcq_params* p;
+    const uint32_t* seeds;
+    const mcq_outputs* out;
+} job_t;
+
+static int64_t ulp_distance(double a, double b) {
+    int64_t x, y;
+    memcpy(&x, &a, 8);
+    memcpy(&y, &b, 8);
+    return x > y ? x - y : y - x; /* both are non-negative finite here */
+}
+
+/* experiments.py:238-239 / 326-327: the uniform is drawn on every step */
+static int accept_move(mt_t* rng, double beta, int dE, int64_t* near_ties) {
+    double e = exp(-beta * (double)dE);
+    double prob = e < 1.0 ? e : 1.0; /* min(1.0, e); NaN cannot occur for finite beta */
+    double u = mt_double(rng);
+    if (near_ties && prob < 1.0 && ulp_distance(u, prob) <= 4) (*near_ties)++;
+    return u < prob;
+}
+
+static int run_board_chain(const job_t* jb, int64_t r) {
+    const mcq_params* p = jb->p;
+    const mcq_outputs* o = jb->out;
+    const int N = p->N, Q = N * N;
+    int* h = (int*)malloc(sizeof(int) * (size_t)Q * 2);
+    int* best_h = h + Q;
+    if (!h) return MCQ_ENOMEM;
+
+    mt_t rng;
+    mt_seed(&rng, jb->seeds[r]); /* experiments.py:287-288 */
+    if (board_init(N, p->init, &rng, h) != 0) {
+        free(h);
+        return MCQ_EINVAL;
+    }
+    int E = board_energy(N, h); /* experiments.py:291 */
+    memcpy(best_h, h, sizeof(int) * (size_t)Q);
+    int best = E;
+    int64_t best_step = 0, accepted = 0, no_improve = 0, ties = 0, len = 1, executed = 0;
+
+    int32_t* hist = o->energy_hist ? o->energy_hist + r * p->hist_stride : NULL;
+    uint64_t* bits = o->accept_bits ? o->accept_bits + r * p->bits_stride : NULL;
+    if (hist) hist[0] = E;
+    if (bits)
+        for (int64_t w = 0; w < p->bits_stride; w++) bits[w] = 0;
+    if (o->initial_energy) o->initial_energy[r] = E;
+
+    for (int64_t step = 0; step < p->n_steps; step++) { /* experiments.py:308-358 */
+        double beta = beta_at(p, step);
+        int i = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        int j = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        int old_k = h[i * N + j];
+        int old_c = board_conflicts(N, h, i, j, old_k);
+        int new_k = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        while (new_k == old_k) new_k = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        int new_c = board_conflicts(N, h, i, j, new_k);
+        int dE = new_c - old_c;
+        int acc = accept_move(&rng, beta, dE, &ties);
+        executed++;
+        int improved = 0;
+        if (acc) {
+            if (bits) bits[step >> 6] |= 1ull << (step & 63);
+            h[i * N + j] = new_k;
+            E += dE;
+            accepted++;
+            if (E < best) {
+                best = E;
+                memcpy(best_h, h, sizeof(int) * (size_t)Q);
+                no_improve = 0;
+                improved = 1;
+            } else {
+                no_improve++;
+            }
+        } else {
+            no_improve++;
+        }
+        if (p->patience >= 0 && no_improve >= p->patience) break; /* before the append: experiments.py:349-353 */
+        if (hist) hist[len] = E;
+        if (improved) best_step = len;
+        len++;
+    }
+    /* steps_to_best = first argmin of energy_history (experiments.py:364-365).  best only
+     * decreases strictly, so the first index holding the minimum is the entry appended by
+     * the last strict improvement (0 if none was appended). */
+    if (o->hist_len) o->hist_len[r] = len;
+    if (o->steps_executed) o->steps_executed[r] = executed;
+    if (o->best_energy) o->best_energy[r] = best;
+    if (o->final_energy) o->final_energy[r] = E;
+    if (o->steps_to_best) o->steps_to_best[r] = best_step;
+    if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->near_ties) o->near_ties[r] = ties;
+    if (o->best_state)
+        for (int c = 0; c < Q; c++) o->best_state[r * Q + c] = (uint8_t)best_h[c];
+    if (o->final_state)
+        for (int c = 0; c < Q; c++) o->final_state[r * Q + c] = (uint8_t)h[c];
+    free(h);
+    return MCQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Full-3D chain: State3DQueens (mcmc.py) + metropolis_mcmc (experiments.py:199-279)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int i, j, k;
+} cell_t;
+
+/* the seven predicates of mcmc.py:148-166 / 205-224 */
+static int full_attacks(cell_t a, cell_t b) {
+    int di = iabs(b.i - a.i), dj = iabs(b.j - a.j), dk = iabs(b.k - a.k);
+    int same_ij = (b.i == a.i) && (b.j == a.j);
+    int same_ik = (b.i == a.i) && (b.k == a.k);
+    int same_jk = (b.j == a.j) && (b.k == a.k);
+    int plane_k = (b.k == a.k) && (di == dj);
+    int plane_j = (b.j == a.j) && (di == dk);
+    int plane_i = (b.i == a.i) && (dj == dk);
+    int space = (di == dj) && (dj == dk);
+    return same_ij | same_ik | same_jk | plane_k | plane_j | plane_i | space;
+}
+
+static int full_init(int N, int init, mt_t* rng, cell_t* q, uint8_t* occ) {
+    const int Q = N * N;
+    memset(occ, 0, (size_t)N * N * N);
+    if (init == MCQ_INIT_LATIN) { /* mcmc.py:28-34 */
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) q[i * N + j] = (cell_t){i, j, (i + j) % N};
+    } else if (init == MCQ_INIT_KLARNER) { /* mcmc.py:36-90 */
+        if (gcd_int(N, 210) == 1) {
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++) q[i * N + j] = (cell_t){i, j, (3 * i + 5 * j) % N};
+        } else {
+            int M = klarner_core(N);
+            if (M == 0) return -1;
+            int n = 0;
+            for (int i = 0; i < M; i++)
+                for (int j = 0; j < M; j++) {
+                    q[n] = (cell_t){i, j, (3 * i + 5 * j) % M};
+                    occ[(q[n].i * N + q[n].j) * N + q[n].k] = 1; /* `used` set, mcmc.py:70 */
+                    n++;
+                }
+            while (n < Q) { /* mcmc.py:81-88 */
+                int i = (int)mt_bounded(rng, (uint32_t)(N - 1));
+                int j = (int)mt_bounded(rng, (uint32_t)(N - 1));
+                int k = (int)mt_bounded(rng, (uint32_t)(N - 1));
+                if (!occ[(i * N + j) * N + k]) {
+                    occ[(i * N + j) * N + k] = 1;
+                    q[n++] = (cell_t){i, j, k};
+                }
+            }
+            memset(occ, 0, (size_t)N * N * N);
+        }
+    } else if (init == MCQ_INIT_RANDOM) { /* mcmc.py:92-101 */
+        /* np.random.choice(N^3, size=Q, replace=False) == permutation(N^3)[:Q]; the legacy
+         * shuffle walks t = n-1 .. 1 and swaps with bounded(t). */
+        int n = N * N * N;
+        int* arr = (int*)malloc(sizeof(int) * (size_t)n);
+        if (!arr) return -1;
+        for (int t = 0; t < n; t++) arr[t] = t;
+        for (int t = n - 1; t >= 1; t--) {
+            int s = (int)mt_bounded(rng, (uint32_t)t);
+            int tmp = arr[t];
+            arr[t] = arr[s];
+            arr[s] = tmp;
+        }
+        for (int c = 0; c < Q; c++) {
+            int f = arr[c];
+            q[c] = (cell_t){f / (N * N), (f / N) % N, f % N};
+        }
+        free(arr);
+    } else {
+        return -1;
+    }
+    for (int c = 0; c < Q; c++) { /* occ_set, mcmc.py:113-118 */
+        size_t f = ((size_t)q[c].i * N + q[c].j) * N + q[c].k;
+        if (occ[f]) return -2;
+        occ[f] = 1;
+    }
+    return 0;
+}
+
+/* mcmc.py:134-169 */
+static int full_energy(int Q, const cell_t* q) {
+    int e = 0;
+    if (Q < 2) return 0;
+    for (int a = 0; a < Q; a++)
+        for (int b = a + 1; b < Q; b++) e += full_attacks(q[a], q[b]);
+    return e;
+}
+
+/* mcmc.py:185-226: queen q_idx removed by index, every other queen tested against `at` */
+static int full_conflicts(int Q, const cell_t* q, int q_idx, cell_t at) {
+    int c = 0;
+    for (int b = 0; b < Q; b++)
+        if (b != q_idx) c += full_attacks(at, q[b]);
+    return c;
+}
+
+static int run_full_chain(const job_t* jb, int64_t r) {
+    const mcq_params* p = jb->p;
+    const mcq_outputs* o = jb->out;
+    const int N = p->N, Q = N * N;
+    cell_t* q = (cell_t*)malloc(sizeof(cell_t) * (size_t)Q * 2);
+    uint8_t* occ = (uint8_t*)malloc((size_t)N * N * N);
+    if (!q || !occ) {
+        free(q);
+        free(occ);
+        return MCQ_ENOMEM;
+    }
+    cell_t* best_q = q + Q;
+
+    mt_t rng;
+    mt_seed(&rng, jb->seeds[r]); /* experiments.py:200-201 */
+    if (full_init(N, p->init, &rng, q, occ) != 0) {
+        free(q);
+        free(occ);
+        return MCQ_EINVAL;
+    }
+    int E = full_energy(Q, q); /* experiments.py:204 */
+    memcpy(best_q, q, sizeof(cell_t) * (size_t)Q);
+    int best = E;
+    int64_t best_step = 0, accepted = 0, ties = 0, len = 1;
+
+    int32_t* hist = o->energy_hist ? o->energy_hist + r * p->hist_stride : NULL;
+    uint64_t* bits = o->accept_bits ? o->accept_bits + r * p->bits_stride : NULL;
+    if (hist) hist[0] = E;
+    if (bits)
+        for (int64_t w = 0; w < p->bits_stride; w++) bits[w] = 0;
+    if (o->initial_energy) o->initial_energy[r] = E;
+
+    for (int64_t step = 0; step < p->n_steps; step++) { /* experiments.py:218-258; early stop is ignored here */
+        double beta = beta_at(p, step);
+        int qi = (int)mt_bounded(&rng, (uint32_t)(Q - 1));
+        int old_c = full_conflicts(Q, q, qi, q[qi]);
+        cell_t nw;
+        for (;;) { /* experiments.py:226-231 */
+            nw.i = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+            nw.j = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+            nw.k = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+            if (!occ[(nw.i * N + nw.j) * N + nw.k]) break;
+        }
+        int new_c = full_conflicts(Q, q, qi, nw);
+        int dE = new_c - old_c;
+        int acc = accept_move(&rng, beta, dE, &ties);
+        if (acc) {
+            if (bits) bits[step >> 6] |= 1ull << (step & 63);
+            occ[(q[qi].i * N + q[qi].j) * N + q[qi].k] = 0; /* mcmc.py:178-181 */
+            occ[(nw.i * N + nw.j) * N + nw.k] = 1;
+            q[qi] = nw;
+            E += dE;
+            accepted++;
+            if (E < best) {
+                best = E;
+                memcpy(best_q, q, sizeof(cell_t) * (size_t)Q);
+                best_step = len;
+            }
+        }
+        if (hist) hist[len] = E;
+        len++;
+    }
+    if (o->hist_len) o->hist_len[r] = len;
+    if (o->steps_executed) o->steps_executed[r] = p->n_steps;
+    if (o->best_energy) o->best_energy[r] = best;
+    if (o->final_energy) o->final_energy[r] = E;
+    if (o->steps_to_best) o->steps_to_best[r] = best_step;
+    if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->near_ties) o->near_ties[r] = ties;
+    for (int c = 0; c < Q; c++) {
+        if (o->best_state) {
+            uint8_t* d = o->best_state + ((size_t)r * Q + c) * 3;
+            d[0] = (uint8_t)best_q[c].i, d[1] = (uint8_t)best_q[c].j, d[2] = (uint8_t)best_q[c].k;
+        }
+        if (o->final_state) {
+            uint8_t* d = o->final_state + ((size_t)r * Q + c) * 3;
+            d[0] = (uint8_t)q[c].i, d[1] = (uint8_t)q[c].j, d[2] = (uint8_t)q[c].k;
+        }
+    }
+    free(q);
+    free(occ);
+    return MCQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fan-out: one task per chain, chain r seeded with seeds[r] (experiments.py:507-517)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const job_t* jb;
+    int64_t next;
+    int rc;
+    pthread_mutex_t mu;
+} pool_t;
+
+static int run_one(const job_t* jb, int64_t r) {
+    return jb->p->mode == MCQ_MODE_BOARD ? run_board_chain(jb, r) : run_full_chain(jb, r);
+}
+
+static void* worker(void* arg) {
+    pool_t* pl = (pool_t*)arg;
+    for (;;) {
+        pthread_mutex_lock(&pl->mu);
+        int64_t r = pl->next++;
+        pthread_mutex_unlock(&pl->mu);
+        if (r >= pl->jb->p->n_chains) break;
+        int rc = run_one(pl->jb, r);
+        if (rc != MCQ_OK) {
+            pthread_mutex_lock(&pl->mu);
+            pl->rc = rc;
+            pthread_mutex_unlock(&pl->mu);
+        }
+    }
+    return NULL;
+}
+
+int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads) {
+    if (!p || !seeds || !out) return fail(MCQ_EINVAL, "null argument");
+    if (p->abi_version != MCQ_ABI_VERSION) return fail(MCQ_EINVAL, "abi_version mismatch");
+    if (p->N < MCQ_MIN_N || p->N > MCQ_MAX_N) return fail(MCQ_EINVAL, "N out of range");
+    if (p->mode != MCQ_MODE_BOARD && p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "unknown mcmc_type");
+    if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
+    if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL)
+        return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
+    if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "unknown rng");
+    if (p->n_steps < 0 || p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_steps / n_chains");
+    if (out->energy_hist && p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
+    if (out->accept_bits && p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
+    if (p->trace == MCQ_TRACE_I32 && (!out->energy_hist || !out->accept_bits))
+        return fail(MCQ_EINVAL, "trace requested without buffers");
+
+    job_t jb = {p, seeds, out};
+    if (n_threads <= 1) {
+        for (int64_t r = 0; r < p->n_chains; r++) {
+            int rc = run_one(&jb, r);
+            if (rc != MCQ_OK) return fail(rc, "chain failed");
+        }
+        return MCQ_OK;
+    }
+    pool_t pl = {&jb, 0, MCQ_OK, PTHREAD_MUTEX_INITIALIZER};
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    if (!th) return fail(MCQ_ENOMEM, "out of memory");
+    int started = 0;
+    for (; started < n_threads; started++)
+        if (pthread_create(&th[started], NULL, worker, &pl) != 0) break;
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+    if (started == 0) return fail(MCQ_ENOMEM, "could not start threads");
+    if (pl.rc != MCQ_OK) return fail(pl.rc, "chain failed");
+    return MCQ_OK;
+}

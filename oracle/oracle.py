@@ -1,0 +1,79 @@
+"""Loader for the CPU oracle (oracle/mcq_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
+the product package never does.  The oracle shares the parameter / output structs of
+include/mcq.h so that its results can be compared with libmcq_hip.so field by field.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmcq_oracle.so")
+_lib = None
+
+abi = importlib.import_module("monte-carlo-collective_amd.abi")
+
+
+def build(force=False):
+    """gcc-compile the oracle in place (seconds)."""
+    src = os.path.join(_HERE, "mcq_oracle.c")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "mcq.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.run(["make", "-C", _HERE, "-B", "libmcq_oracle.so"], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.mcq_oracle_run.restype = C.c_int
+        L.mcq_oracle_run.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.c_int]
+        L.mcq_oracle_last_error.restype = C.c_char_p
+        L.mcq_oracle_rng_stream.restype = C.c_int
+        L.mcq_oracle_rng_stream.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mcq_oracle_beta_table.restype = C.c_int
+        L.mcq_oracle_beta_table.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def run(params, seeds, trace=True, states=True, n_threads=1):
+    """Run every chain on the CPU; returns {field: ndarray} shaped as abi.output_shapes()."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    assert seeds.shape == (params.n_chains,)
+    arrays = {k: np.zeros(shape, dtype=abi.OUTPUT_DTYPES[k])
+              for k, shape in abi.output_shapes(params, trace=trace, states=states).items()}
+    out = abi.Outputs()
+    for k, a in arrays.items():
+        setattr(out, k, a.ctypes.data)
+    p = abi.Params.from_buffer_copy(params)
+    p.trace = abi.TRACE_I32 if trace else abi.TRACE_NONE
+    rc = lib().mcq_oracle_run(C.byref(p), seeds.ctypes.data, C.byref(out), int(n_threads))
+    if rc != 0:
+        msg = lib().mcq_oracle_last_error().decode()
+        raise (ValueError if rc == abi.EINVAL else RuntimeError)(msg)
+    return arrays
+
+
+def rng_stream(seed, kind, n, arg=0):
+    """kind: 'u32' raw words, 'bounded' masked-rejection integers in [0, arg], 'double'."""
+    code = {"u32": 0, "bounded": 1, "double": 2}[kind]
+    u = np.zeros(n, dtype=np.uint32)
+    d = np.zeros(n, dtype=np.float64)
+    lib().mcq_oracle_rng_stream(int(seed), code, int(arg), n, u.ctypes.data, d.ctypes.data)
+    return d if kind == "double" else u
+
+
+def beta_table(params, steps):
+    steps = np.ascontiguousarray(steps, dtype=np.int64)
+    out = np.zeros(len(steps), dtype=np.float64)
+    lib().mcq_oracle_beta_table(C.byref(params), steps.ctypes.data, len(steps), out.ctypes.data)
+    return out

@@ -1,0 +1,144 @@
+"""The CPU oracle (oracle/mcq_oracle.c) against vectors captured from the reference itself.
+
+This is what pins the oracle: every fixture in tests/golden/ was produced by importing
+/root/reference (tools/gen_golden.py).  CPU-only; runs in seconds.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import util
+
+abi = util.abi
+
+
+def test_every_golden_chain(golden):
+    """F3/F4: energy_history, accept bits, best/final energy and state, steps_to_best
+    (experiments.py:270-279, 367-376) for 190+ reference chains."""
+    assert len(golden.chains) >= 190
+    for case in golden.chains:
+        p = util.params_for_case(case)
+        res = oracle.run(p, np.array([case["seed"]], dtype=np.uint32))
+        util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle vs reference {case}")
+
+
+def test_early_stop_lengths(golden):
+    """F4: board N=6 const beta=5 seed 7 patience 300 stops with 803 entries, best at 503."""
+    case = next(c for c in golden.chains if c.get("patience") == 300)
+    g = golden.chain(case)
+    assert len(g["hist"]) == 803 and int(g["steps_to_best"]) == 503
+    full3d = next(c for c in golden.chains if c.get("patience") == 50)
+    assert len(golden.chain(full3d)["hist"]) == full3d["n_steps"] + 1  # full_3d ignores patience
+
+
+def test_initial_states(golden):
+    """F2: State3DQueensBoard.__init__ / State3DQueens.__init__ (mcmc_board.py:26-59, mcmc.py:20-104) and E0."""
+    z = golden.npz("init")
+    sp = {"type": "constant", "beta_const": 1.0}
+    for c in golden.manifest["init"]:
+        p = abi.make_params(c["N"], 0, c["init"], sp, 1, mcmc_type=c["mode"])
+        res = oracle.run(p, np.array([c["seed"]], dtype=np.uint32))
+        np.testing.assert_array_equal(res["final_state"][0], z[c["key"]], err_msg=str(c))
+        assert int(res["initial_energy"][0]) == c["E0"], c
+
+
+def test_init_consumes_the_same_words(golden):
+    """After init the next draw of the stream matches: pins how many MT words each init mode used."""
+    # a 1-step chain draws i = bounded(N-1) first; compare through the raw stream instead:
+    # replay the init in NumPy terms is not possible here, so use the recorded next randint.
+    for c in golden.manifest["init"]:
+        if c["mode"] != "board" or c["init"] != "random":
+            continue
+        N = c["N"]
+        words = oracle.rng_stream(c["seed"], "bounded", N * N + 1, arg=N - 1)  # same-mask prefix
+        assert words[: N * N].tolist() == golden.npz("init")[c["key"]].tolist()
+
+
+def test_analytic_known_answers(golden):
+    """F7: latin E0 for N=2..24 (board == full_3d) and klarner E0 == 0 when gcd(N,210)==1."""
+    a = golden.manifest["analytic"]
+    sp = {"type": "constant", "beta_const": 1.0}
+    assert a["latin_board"] == a["latin_full_3d"]
+    assert [a["latin_board"][str(n)] for n in (2, 3, 4, 11, 12, 24)] == [6, 18, 54, 1155, 1674, 13596]
+    for mode in ("board", "full_3d"):
+        for N in range(2, 25):
+            p = abi.make_params(N, 0, "latin", sp, 1, mcmc_type=mode)
+            assert int(oracle.run(p, np.zeros(1, np.uint32))["initial_energy"][0]) == a["latin_board"][str(N)]
+        for N in (11, 13, 17, 19, 23):
+            p = abi.make_params(N, 0, "klarner", sp, 1, mcmc_type=mode)
+            assert int(oracle.run(p, np.zeros(1, np.uint32))["initial_energy"][0]) == 0
+
+
+def test_plumbing_vector(golden):
+    """F6: BASELINE config 1 (N=6 board random constant beta=5, 4 runs x 1e4 steps, seeds 42..45)
+    as returned by the reference's run_experiment (experiments.py:475-573)."""
+    pl = golden.manifest["plumbing"]
+    assert pl["E0"] == [107, 114, 99, 96] and pl["best"] == [50, 53, 55, 49]
+    p = abi.make_params(pl["N"], pl["n_steps"], pl["init"], pl["schedule"], pl["n_runs"], mcmc_type=pl["mode"])
+    res = oracle.run(p, abi.seeds_for(pl["base_seed"], pl["n_runs"]), n_threads=2)
+    assert res["initial_energy"].tolist() == pl["E0"]
+    assert res["best_energy"].tolist() == pl["best"]
+    assert res["steps_to_best"].tolist() == pl["steps_to_best"]
+    assert res["n_accepted"].tolist() == pl["n_accepted"]
+    assert res["final_energy"].tolist() == pl["final"]
+    for r in range(pl["n_runs"]):
+        h = res["energy_hist"][r, : pl["n_steps"] + 1].astype(np.int64)
+        crc = int(np.bitwise_xor.reduce((h * (np.arange(len(h)) + 1)) & 0x7FFFFFFF))
+        assert crc == pl["hist_crc"][r]
+
+
+def test_beta_tables(golden):
+    """F5: the five schedule closures (experiments.py:13-77) as float64.  Linear, logarithmic and
+    sinusoidal tables are bit-equal; np.exp (SIMD) and libm exp may differ in the last place, so the
+    exponential schedule is allowed 1 ulp."""
+    z = golden.npz("beta")
+    for c in golden.manifest["beta"]:
+        p = abi.make_params(6, c["n_steps"], "random", c["schedule"], 1, mcmc_type="board")
+        got = oracle.beta_table(p, z[c["key"] + "_steps"])
+        want = z[c["key"] + "_beta"]
+        if c["schedule"]["type"] == "exponential_annealing":
+            ulp = np.abs(got.view(np.int64) - want.view(np.int64))
+            assert ulp.max() <= 1, c
+        else:
+            np.testing.assert_array_equal(got, want, err_msg=str(c))
+
+
+def test_threads_do_not_change_results():
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    p = abi.make_params(7, 500, "random", sp, 13, mcmc_type="full_3d")
+    seeds = abi.seeds_for(100, 13)
+    a = oracle.run(p, seeds, n_threads=1)
+    b = oracle.run(p, seeds, n_threads=4)
+    util.assert_results_equal(a, b, "oracle 1 vs 4 threads")
+
+
+def test_sum_of_conflicts_is_twice_energy():
+    """Sum over queens of conflicts(q) == 2 E for any state: checked through dE bookkeeping --
+    the running energy after many accepted moves equals a fresh pairwise recount of the final state."""
+    sp = {"type": "constant", "beta_const": 0.5}
+    for mode in ("board", "full_3d"):
+        p = abi.make_params(7, 400, "random", sp, 3, mcmc_type=mode)
+        res = oracle.run(p, abi.seeds_for(5, 3))
+        for r in range(3):
+            st = res["final_state"][r]
+            if mode == "board":
+                cells = [(c // 7, c % 7, int(k)) for c, k in enumerate(st)]
+            else:
+                cells = [tuple(int(x) for x in st[3 * q: 3 * q + 3]) for q in range(49)]
+            e = 0
+            for a in range(49):
+                for b in range(a + 1, 49):
+                    d = [abs(cells[a][t] - cells[b][t]) for t in range(3)]
+                    nz = [x for x in d if x]
+                    e += len(nz) > 0 and len(set(nz)) == 1  # same line: all non-zero offsets equal
+            assert e == int(res["final_energy"][r])
+
+
+@pytest.mark.parametrize("bad", [dict(init_mode="spiral"), dict(schedule_params={"type": "cubic"}),
+                                 dict(schedule_params={"type": "linear_annealing", "beta_start": 1.0})])
+def test_value_errors_match_reference(bad):
+    """ValueError for unknown schedule / init and missing beta parameters (experiments.py:85-105, mcmc_board.py:59)."""
+    kw = dict(N=6, n_steps=10, init_mode="random", schedule_params={"type": "constant", "beta_const": 1.0}, n_chains=1)
+    kw.update(bad)
+    with pytest.raises(ValueError):
+        abi.make_params(**kw)
