@@ -134,6 +134,13 @@ int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs
                    void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /*
+ * mcq_run_device plus HIP events recorded on `hip_stream` around the init kernel and around the
+ * sweep kernel; waits for the last event and returns both device times in milliseconds.  Blocking.
+ */
+int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
+                         size_t workspace_bytes, void* hip_stream, float* init_ms, float* sweep_ms);
+
+/*
  * Same computation with HOST buffers: allocates device memory, uploads seeds, runs,
  * downloads every non-NULL output and frees.  Blocking.  `kernel_seconds` (optional)
  * receives the device time of init + sweep measured with HIP events.

@@ -1,0 +1,168 @@
+"""ctypes binding of libmcq_hip.so -- the only compute path of this package.
+
+There is deliberately no CPU fallback: if the library is missing or no GPU is present the
+calls raise.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+from . import abi, build as _build
+
+_lib = None
+
+
+class McqError(RuntimeError):
+    pass
+
+
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both open the GPU, and streams / events of one are meaningless
+    to the other, so when torch is installed its runtime is loaded first (RTLD_GLOBAL): the dynamic
+    linker then binds libmcq_hip.so's NEEDED libamdhip64.so.7 to it, and a later `import torch`
+    finds it already mapped.  MCQ_HIP_RUNTIME=system skips this (pure-ctypes users without torch)."""
+    if os.environ.get("MCQ_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
+def lib():
+    """Load csrc/libmcq_hip.so (building it if the sources are newer and hipcc exists)."""
+    global _lib
+    if _lib is None:
+        _share_torch_hip_runtime()
+        so = _build.SO
+        if _build.stale():
+            try:
+                _build.build()
+            except RuntimeError as e:
+                if not os.path.exists(so):
+                    raise McqError(f"libmcq_hip.so is not built and could not be built: {e}") from e
+        try:
+            L = C.CDLL(so)
+        except OSError as e:
+            raise McqError(f"cannot load {so}: {e}") from e
+        L.mcq_abi_version.restype = C.c_int
+        L.mcq_last_error.restype = C.c_char_p
+        L.mcq_device_count.restype = C.c_int
+        L.mcq_state_bytes.restype = C.c_size_t
+        L.mcq_state_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.mcq_workspace_bytes.restype = C.c_size_t
+        L.mcq_workspace_bytes.argtypes = [C.POINTER(abi.Params)]
+        L.mcq_run_device.restype = C.c_int
+        L.mcq_run_device.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mcq_run_device_timed.restype = C.c_int
+        L.mcq_run_device_timed.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.mcq_run_host.restype = C.c_int
+        L.mcq_run_host.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.POINTER(C.c_double)]
+        if L.mcq_abi_version() != abi.ABI_VERSION:
+            raise McqError("libmcq_hip.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == abi.OK:
+        return
+    msg = lib().mcq_last_error().decode(errors="replace")
+    if rc == abi.EINVAL:
+        raise ValueError(msg)
+    if rc == abi.ENOMEM:
+        raise MemoryError(msg)
+    raise McqError(msg)
+
+
+def device_count():
+    return lib().mcq_device_count()
+
+
+def run_host(params, seeds, trace=True, states=True):
+    """All chains on the GPU with NumPy (host) buffers; returns ({field: ndarray}, kernel_seconds)."""
+    L = lib()
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    if seeds.shape != (params.n_chains,):
+        raise ValueError("seeds must have one entry per chain")
+    p = abi.Params.from_buffer_copy(params)
+    p.trace = abi.TRACE_I32 if trace else abi.TRACE_NONE
+    arrays = {k: np.zeros(shape, dtype=abi.OUTPUT_DTYPES[k])
+              for k, shape in abi.output_shapes(p, trace=trace, states=states).items()}
+    out = abi.Outputs()
+    for k, a in arrays.items():
+        setattr(out, k, a.ctypes.data)
+    secs = C.c_double(0.0)
+    _check(L.mcq_run_host(C.byref(p), seeds.ctypes.data, C.byref(out), C.byref(secs)))
+    return arrays, secs.value
+
+
+class DeviceRun:
+    """Device-resident buffers for repeated launches (bench.py, multi-GPU driver).
+
+    torch is used only as the allocator / stream provider; the kernels are launched by
+    libmcq_hip.so through raw device pointers."""
+
+    def __init__(self, params, seeds, trace=True, states=True, device=None):
+        import torch
+
+        self.torch = torch
+        self.L = lib()
+        self.p = abi.Params.from_buffer_copy(params)
+        self.p.trace = abi.TRACE_I32 if trace else abi.TRACE_NONE
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        tdt = {np.int32: torch.int32, np.int64: torch.int64, np.uint8: torch.uint8, np.uint64: torch.int64}
+        self.t = {}
+        self.out = abi.Outputs()
+        with torch.cuda.device(self.device):
+            for k, shape in abi.output_shapes(self.p, trace=trace, states=states).items():
+                self.t[k] = torch.empty(shape, dtype=tdt[abi.OUTPUT_DTYPES[k]], device=self.device)
+                setattr(self.out, k, self.t[k].data_ptr())
+            s = np.ascontiguousarray(seeds, dtype=np.uint32)
+            if s.shape != (self.p.n_chains,):
+                raise ValueError("seeds must have one entry per chain")
+            self.seeds = torch.from_numpy(s.view(np.int32).copy()).to(self.device)
+            self.ws_bytes = int(self.L.mcq_workspace_bytes(C.byref(self.p)))
+            if self.ws_bytes == 0:
+                _check(abi.EINVAL)
+            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+
+    def launch(self, stream=None):
+        """Enqueue init + sweep on `stream` (default: torch's current stream); asynchronous."""
+        torch = self.torch
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        with torch.cuda.device(self.device):
+            _check(self.L.mcq_run_device(C.byref(self.p), self.seeds.data_ptr(), C.byref(self.out),
+                                         self.ws.data_ptr(), self.ws_bytes, C.c_void_p(st.cuda_stream)))
+
+    def launch_timed(self, stream=None):
+        """Like launch(), but brackets the init and sweep kernels with HIP events recorded on the launch
+        stream and waits for them; returns (init_ms, sweep_ms)."""
+        torch = self.torch
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        i_ms, s_ms = C.c_float(0), C.c_float(0)
+        with torch.cuda.device(self.device):
+            _check(self.L.mcq_run_device_timed(C.byref(self.p), self.seeds.data_ptr(), C.byref(self.out), self.ws.data_ptr(),
+                                               self.ws_bytes, C.c_void_p(st.cuda_stream), C.byref(i_ms), C.byref(s_ms)))
+        return i_ms.value, s_ms.value
+
+    def results(self):
+        """Copy every output back as NumPy arrays (synchronises)."""
+        res = {}
+        for k, t in self.t.items():
+            a = t.cpu().numpy()
+            res[k] = a.view(np.uint64) if abi.OUTPUT_DTYPES[k] is np.uint64 else a
+        return res

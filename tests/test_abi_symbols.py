@@ -1,0 +1,62 @@
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every function include/mcq.h
+declares for it (no compute call is made: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import mcq_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mcq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"\b(mcq_\w+)\s*\(", src)
+
+
+def test_header_symbols_are_exported():
+    names = _declared()
+    hip = [n for n in names if not n.startswith("mcq_oracle")]
+    assert {"mcq_run_device", "mcq_run_host", "mcq_workspace_bytes", "mcq_state_bytes", "mcq_abi_version",
+            "mcq_last_error", "mcq_device_count"} <= set(hip)
+    L = mcq_amd._lib.lib()
+    for n in hip:
+        assert hasattr(L, n), n
+    assert L.mcq_abi_version() == mcq_amd.abi.ABI_VERSION
+
+
+def test_oracle_symbols_are_exported():
+    from oracle import oracle
+
+    L = oracle.lib()
+    for n in _declared():
+        if n.startswith("mcq_oracle"):
+            assert hasattr(L, n), n
+
+
+def test_struct_layout_matches_header():
+    """sizeof / field order of the ctypes mirrors against a C compiler's view of the header."""
+    import subprocess
+    import tempfile
+
+    abi = mcq_amd.abi
+    fields = [f for f, _ in abi.Params._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "mcq.h"\nint main(){printf("%zu %zu", sizeof(mcq_params), sizeof(mcq_outputs));' + \
+        "".join(f'printf(" %zu", offsetof(mcq_params, {f}));' for f in fields) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(abi.Params) and int(out[1]) == ctypes.sizeof(abi.Outputs)
+    assert [int(x) for x in out[2:]] == [getattr(abi.Params, f).offset for f in fields]
+
+
+def test_pure_helpers_without_gpu():
+    L = mcq_amd._lib.lib()
+    assert L.mcq_state_bytes(12, 0) == 144 and L.mcq_state_bytes(12, 1) == 432 and L.mcq_state_bytes(1, 0) == 0
+    p = mcq_amd.abi.make_params(12, 1000, "random", {"type": "constant", "beta_const": 1.0}, 10, mcmc_type="board")
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == 10 * (628 + 36) * 4
+    p.N = 99
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0
+    assert b"N out of range" in L.mcq_last_error()

@@ -1,0 +1,130 @@
+"""GPU parity: the HIP kernels, called through the C-ABI (mcq_run_host / mcq_run_device), against
+(a) the golden vectors captured from the reference and (b) the CPU oracle on fresh seeded inputs.
+Integer outputs must be bit-identical: energy_history, accept bits, best / final energy and state,
+steps_to_best, history length (experiments.py:270-279, 367-376)."""
+import itertools
+
+import numpy as np
+import pytest
+
+import mcq_amd
+from oracle import oracle
+from tests import util
+
+abi = mcq_amd.abi
+pytestmark = pytest.mark.gpu
+LANES = (16, 32, 64)
+
+
+def _group_key(c):
+    return (c["mode"], c["init"], c["N"], c["n_steps"], c.get("patience"), tuple(sorted(c["schedule"].items())))
+
+
+@pytest.mark.parametrize("lanes", LANES)
+def test_golden_chains(golden, lanes):
+    """Every reference chain of tests/golden, batched by parameter set (seeds differ inside a launch)."""
+    cases = sorted(golden.chains, key=lambda c: str(_group_key(c)))
+    n = 0
+    for _, grp in itertools.groupby(cases, key=lambda c: str(_group_key(c))):
+        grp = list(grp)
+        p = util.params_for_case(grp[0], n_chains=len(grp), lanes_per_chain=lanes)
+        res, _ = mcq_amd._lib.run_host(p, np.array([c["seed"] for c in grp], dtype=np.uint32))
+        for r, c in enumerate(grp):
+            util.assert_chain_equals_golden(res, r, c, golden.chain(c), f"hip G={lanes} vs reference {c}")
+            n += 1
+    assert n == len(golden.chains)
+
+
+CASES = [
+    # (N, mode, init, schedule, n_steps, n_chains, patience)
+    (12, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 3000, 150, None),
+    (12, "full_3d", "random", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 1500, 70, None),
+    (24, "board", "random", {"type": "sinusoidal_annealing", "beta_start": 0.1, "beta_end": 5.0}, 1200, 40, None),
+    (7, "board", "klarner", {"type": "logarithmic_annealing", "beta_start": 0.5, "beta_end": 3.0}, 2000, 33, 120),
+    (5, "full_3d", "klarner", {"type": "constant", "beta_const": 0.7}, 1000, 21, None),
+    (20, "full_3d", "latin", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 2.0}, 400, 9, None),
+    (3, "board", "latin", {"type": "constant", "beta_const": 0.0}, 700, 17, None),
+    (32, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 2.0}, 300, 5, None),
+    (2, "full_3d", "random", {"type": "constant", "beta_const": 2.0}, 500, 6, None),
+]
+
+
+@pytest.mark.parametrize("lanes", LANES)
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"N{c[0]}-{c[1]}-{c[2]}-{c[3]['type']}")
+def test_hip_equals_oracle(case, lanes):
+    N, mode, init, sp, n_steps, n_chains, patience = case
+    p = abi.make_params(N, n_steps, init, sp, n_chains, mcmc_type=mode, early_stop_patience=patience, lanes_per_chain=lanes)
+    seeds = abi.seeds_for(9000 + 17 * N, n_chains)
+    want = oracle.run(p, seeds, n_threads=8)
+    got, secs = mcq_amd._lib.run_host(p, seeds)
+    util.assert_results_equal(got, want, f"hip G={lanes} vs oracle {case}")
+    assert got["near_ties"].sum() == 0 and want["near_ties"].sum() == 0
+    assert secs > 0
+
+
+def test_exact_exp_flag_changes_nothing():
+    """The float32 bracket around exp(-beta*dE) never decides differently from float64 on every step."""
+    sp = {"type": "linear_annealing", "beta_start": 0.2, "beta_end": 3.0}
+    for mode in ("board", "full_3d"):
+        seeds = abi.seeds_for(31337, 96)
+        a, _ = mcq_amd._lib.run_host(abi.make_params(9, 4000, "random", sp, 96, mcmc_type=mode), seeds)
+        b, _ = mcq_amd._lib.run_host(abi.make_params(9, 4000, "random", sp, 96, mcmc_type=mode, flags=abi.FLAG_EXACT_EXP), seeds)
+        util.assert_results_equal(a, b, f"bracketed vs exact exp ({mode})")
+
+
+def test_trace_none_matches_trace_i32():
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    p = abi.make_params(12, 2500, "random", sp, 64, mcmc_type="board")
+    seeds = abi.seeds_for(5, 64)
+    full, _ = mcq_amd._lib.run_host(p, seeds, trace=True)
+    lean, _ = mcq_amd._lib.run_host(p, seeds, trace=False)
+    util.assert_results_equal(full, lean, "trace i32 vs none", trace=False)
+
+
+def test_ragged_chain_counts_and_tail_blocks():
+    """n_chains not a multiple of the chains per wavefront, n_steps around the 16/32/64-entry block edges."""
+    sp = {"type": "constant", "beta_const": 1.5}
+    for n_steps in (0, 1, 15, 16, 31, 63, 64, 65, 127, 128, 129):
+        for n_chains in (1, 3, 5):
+            p = abi.make_params(6, n_steps, "random", sp, n_chains, mcmc_type="board")
+            seeds = abi.seeds_for(77, n_chains)
+            want = oracle.run(p, seeds)
+            for lanes in LANES:
+                p.lanes_per_chain = lanes
+                got, _ = mcq_amd._lib.run_host(p, seeds)
+                util.assert_results_equal(got, want, f"n_steps={n_steps} n_chains={n_chains} G={lanes}")
+
+
+def test_device_pointer_entry_point():
+    """mcq_run_device with torch-allocated device buffers on a non-default stream."""
+    import torch
+
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    p = abi.make_params(12, 2000, "random", sp, 100, mcmc_type="board")
+    seeds = abi.seeds_for(42, 100)
+    run = mcq_amd._lib.DeviceRun(p, seeds)
+    st = torch.cuda.Stream()
+    run.launch(stream=st)
+    st.synchronize()
+    util.assert_results_equal(run.results(), oracle.run(p, seeds, n_threads=8), "mcq_run_device vs oracle")
+
+
+def test_run_experiment_plumbing(golden):
+    """BASELINE config 1 through the drop-in run_experiment: the reference's 6-tuple (experiments.py:573)."""
+    pl = golden.manifest["plumbing"]
+    sched = mcq_amd.build_schedule_from_params("constant", pl["n_steps"], beta_const=5.0)
+    hist, best, times, acc, rej, stb = mcq_amd.run_experiment(
+        N=pl["N"], n_steps=pl["n_steps"], init_mode=pl["init"], beta_schedule=sched, n_runs=pl["n_runs"],
+        base_seed=pl["base_seed"], schedule_params=pl["schedule"], mcmc_type="board", early_stop_patience=None)
+    assert [int(h[0]) for h in hist] == pl["E0"] and best == pl["best"] and stb == pl["steps_to_best"]
+    assert [len(a) for a in acc] == pl["n_accepted"]
+    assert all(len(a) + len(r) == pl["n_steps"] for a, r in zip(acc, rej)) and len(times) == pl["n_runs"]
+    assert all(len(h) == pl["n_steps"] + 1 for h in hist)
+
+
+def test_errors_cross_the_abi_as_exceptions():
+    sp = {"type": "constant", "beta_const": 1.0}
+    p = abi.make_params(6, 10, "random", sp, 2, mcmc_type="board")
+    p.sched = 9
+    with pytest.raises(ValueError):
+        mcq_amd._lib.run_host(p, abi.seeds_for(0, 2))
