@@ -63,7 +63,8 @@ extern "C" {
 #define MCQ_TRACE_I32 1  /* full int32 trace + accept bits (experiments.py:355, 329-332) */
 
 /* flags */
-#define MCQ_FLAG_EXACT_EXP 1u /* evaluate exp(-beta*dE) in float64 on every step (disable the bracketing pre-filter) */
+#define MCQ_FLAG_EXACT_EXP 1u        /* evaluate exp(-beta*dE) in float64 on every step (disable the float32 bracket) */
+#define MCQ_FLAG_SEQUENTIAL_DRAWS 2u /* HIP: draw every proposal word by word (disable the batched selection); for testing */
 
 /* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319). */
 #define MCQ_MIN_N 2
@@ -86,7 +87,7 @@ typedef struct mcq_params {
     int64_t patience;        /* early_stop_patience, board only (experiments.py:349-353); < 0 = None */
     int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1 */
     int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
-    int32_t lanes_per_chain; /* HIP only: 16, 32 or 64 lanes of a wavefront per chain; 0 = library default */
+    int32_t lanes_per_chain; /* HIP only: 8 or 16 lanes of a wavefront per chain; 0 = library default */
     int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
 } mcq_params;
 

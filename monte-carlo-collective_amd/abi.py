@@ -24,6 +24,7 @@ SCHED = {
 RNG_MT19937_NUMPY = 0
 TRACE_NONE, TRACE_I32 = 0, 1
 FLAG_EXACT_EXP = 1
+FLAG_SEQUENTIAL_DRAWS = 2
 
 MIN_N, MAX_N = 2, 32
 

@@ -8,26 +8,37 @@
 //   beta schedules          experiments.py:13-77
 //   run_experiment fan-out  experiments.py:507-546   (chain r seeded with base_seed + r)
 //
-// Design: a wavefront of 64 lanes is split into groups of G lanes (G = 16,
-// 32 or 64); one group runs one chain.  Everything that is serial in a chain (the NumPy-legacy
-// MT19937 stream with its data-dependent word consumption, the proposal, the accept test) is
-// computed redundantly by the G lanes of the group; the attack count is spread over the lanes.
-//   * MT19937 state: 624 words per chain in LDS, regenerated lazily G words at a time (each
-//     lane twists one word, tempers it and keeps it in a register "window"); a draw is one
-//     ds_bpermute from the window.
-//   * board dE: the only columns that can attack cell (i,j,k) lie on the row, the column and
-//     the two diagonals of (i,j) in the ij-plane, at most 4N of them; a column at in-plane
-//     distance d attacks iff |h - k| is 0 or d.  4N column probes over G lanes + a DPP
-//     all-reduce give conflicts(new) - conflicts(old) without any per-line counters.
-//   * energy_history: each group stages G consecutive entries in one register and stores
-//     them as one aligned G*4-byte segment; accept bits as one 64-bit word per 64 steps.
-//   * beta(step) is evaluated on device in float64, 64 steps at a time (lane L computes
-//     step0 + L), strict IEEE (compiled with -ffp-contract=off).
-//   * exp(-beta*dE) is bracketed by a float32 estimate; only when the uniform falls inside
-//     the bracket (|u/p - 1| < 2^-10) is the float64 exp evaluated, so every decision equals
-//     the all-float64 decision (MCQ_FLAG_EXACT_EXP forces float64 on every step for testing).
+// Design (DESIGN.md has the long form).  A wavefront of 64 lanes is split into groups of G
+// lanes (G = 8 or 16); one group runs one chain, so a wavefront advances 64/G chains in
+// lockstep, one Metropolis step per loop iteration.  What is serial inside a chain (the
+// NumPy-legacy MT19937 stream with its data-dependent word consumption, the proposal, the
+// accept test) is computed redundantly by the G lanes of the group; the attack count and the
+// stream generation are spread over the lanes.
+//   * MT19937: 624 raw state words per chain in LDS.  Words are regenerated G at a time
+//     ("round": every lane twists one word), tempered, and appended to a 64-slot ring of
+//     ready words in LDS, together with one bit per slot that says whether the word passes
+//     the masked-rejection test of randint(0, N).  Rounds run at a fixed cadence for every
+//     chain of the wavefront that has room, so the lanes stay converged.
+//   * proposal (board): the positions of the next four accepted words come from bit tricks
+//     on the 32-slot view of the accept bits (no rejection loop, no divergence); i, j and two
+//     candidates for new_k are fetched in one batch, the uniform's two words sit right after
+//     the chosen candidate.  Anything unusual (ring nearly empty, both candidates equal to
+//     old_k, rejection run longer than the view) takes a sequential fallback that draws word
+//     by word -- same stream, same results.
+//   * dE (board): only columns on the row, column and two diagonals of (i,j) in the ij-plane
+//     can attack cell (i,j,k), at most 4N of them; a column at in-plane distance d with height
+//     h attacks iff |h-k| is 0 or d, i.e. iff bit h of (B | B<<d | B>>d), B = 1<<k, is set.
+//     One lane per (direction, position) probe, then a DPP all-reduce over the group.
+//   * accept: u < exp(-beta dE) is decided in float32 from the top 27 bits of u whenever u is
+//     outside a 2^-10 relative bracket around the float32 estimate; inside the bracket the
+//     float64 exp and the 53-bit u decide, so every decision equals the all-float64 decision.
+//     (MCQ_FLAG_EXACT_EXP disables the bracket.)
+//   * beta(step) is evaluated on the device in float64 by a small kernel into a table that the
+//     sweep reads with scalar loads; strict IEEE (this file is built with -ffp-contract=off).
+//   * energy_history: each group stages G consecutive entries in a register and stores them
+//     as one aligned segment; accept bits are flushed as 64-bit words.
 //
-// This file is compiled for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -39,7 +50,8 @@ namespace {
 
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
-constexpr int REC_POS = 624;      // record word: index of the next MT word to consume
+constexpr int RING = 64;          // ready (tempered) words per chain
+constexpr int REC_POS = 624;      // record word: MT index of the next word to consume
 constexpr int REC_GEN_END = 625;  // record word: words [0, gen_end) belong to the current generation
 constexpr int REC_E0 = 626;       // record word: initial energy
 constexpr int REC_STATE = 628;    // first word of the state bytes (heights or (i,j,k) triplets)
@@ -54,7 +66,8 @@ struct KArgs {
     int chain_lds_words;    // words of LDS per chain in the sweep kernel
     double beta_const, beta_start, beta_end;
     long long n_steps, n_chains, patience, hist_stride, bits_stride;
-    uint32_t* ws;
+    uint32_t* ws;           // chain records
+    double* beta_tab;       // [n_steps] beta(step), filled by mcq_beta_kernel
     const uint32_t* seeds;
     mcq_outputs out;
 };
@@ -67,60 +80,56 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// NumPy-legacy MT19937 stream of one chain, shared by the G lanes of its group.
-//   mt       LDS, 624 raw state words
-//   pos      next word to consume, 0..623
-//   gen_end  words [0, gen_end) already belong to the current generation (multiple of 64, or 624)
-//   win      tempered word (chunk base + lane-in-group) of the chunk that contains pos
-// Word i of a generation depends on words i, i+1 and (i+397) mod 624, the last one from the
-// current generation when i >= 227 and the middle one when i == 623; regenerating chunks of
-// G <= 64 consecutive words in increasing order on demand therefore yields exactly the words
-// of the all-at-once twist in mt19937_gen (NumPy: _mt19937/mt19937.c) -- every lane reads its
-// three inputs before any lane of the chunk writes.
-template <int G>
-struct Rng {
+// One word of the next MT19937 generation.  Word i depends on words i, i+1 and (i+397) mod 624,
+// the last taken from the NEW generation when i >= 227 and the middle one when i == 623;
+// regenerating blocks of <= 64 consecutive words in increasing order on demand therefore yields
+// exactly the words of the all-at-once twist (NumPy: _mt19937/mt19937.c, mt19937_gen) -- every
+// lane of a block reads its three inputs before any lane of the block writes.
+__device__ __forceinline__ uint32_t mt_twist_word(const uint32_t* mt, int i) {
+    const uint32_t a = mt[i];
+    const uint32_t b = mt[i + 1 == MT_N ? 0 : i + 1];
+    const uint32_t c = mt[i + MT_M >= MT_N ? i + MT_M - MT_N : i + MT_M];
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ unsigned mask_for(unsigned m) {
+    unsigned mask = m;
+    mask |= mask >> 1, mask |= mask >> 2, mask |= mask >> 4, mask |= mask >> 8, mask |= mask >> 16;
+    return mask;
+}
+
+// Stream used by the init kernel: one wavefront per chain, the current 64-word block kept in a
+// register per lane, one ds_bpermute per draw.
+struct InitRng {
     uint32_t* mt;
     uint32_t win;
-    int pos, gen_end;
-    int gl;     // lane within the group
-    int gbase;  // wave lane of the group's lane 0
+    int pos, gen_end, lane;
 
     __device__ __forceinline__ void fill(int base) {
-        const int i = base + gl;
+        const int i = base + lane;
         if (i < MT_N) {
             uint32_t v;
             if (base < gen_end) {
                 v = mt[i];
             } else {
-                const uint32_t a = mt[i];
-                const uint32_t b = mt[i + 1 == MT_N ? 0 : i + 1];
-                const uint32_t c = mt[i + MT_M >= MT_N ? i + MT_M - MT_N : i + MT_M];
-                const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-                v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                v = mt_twist_word(mt, i);
                 mt[i] = v;
             }
             win = mt_temper(v);
         }
-        if (base >= gen_end) gen_end = base + G > MT_N ? MT_N : base + G;
+        if (base >= gen_end) gen_end = base + 64 > MT_N ? MT_N : base + 64;
     }
-
-    __device__ __forceinline__ void attach(uint32_t* lds_mt, int p, int ge, int gl_, int gbase_) {
-        mt = lds_mt, pos = p, gen_end = ge, gl = gl_, gbase = gbase_, win = 0;
-        const int off = pos & (G - 1);
-        if (off != 0) fill(pos - off);  // resume in the middle of a chunk: always below gen_end
-    }
-
     __device__ __forceinline__ uint32_t next() {
-        const int off = pos & (G - 1);
+        const int off = pos & 63;
         if (off == 0) fill(pos);
-        const uint32_t w = (uint32_t)__shfl((int)win, gbase + off, 64);
+        const uint32_t w = (uint32_t)__shfl((int)win, off, 64);
         pos++;
         if (pos == MT_N) pos = 0, gen_end = 0;
         return w;
     }
-
-    // RandomState.randint(0, m + 1) / shuffle's random_interval: masked rejection on 32-bit
-    // words; m == 0 consumes nothing.
+    // RandomState.randint(0, m + 1) / shuffle's random_interval: masked rejection on 32-bit words;
+    // m == 0 consumes nothing.
     __device__ __forceinline__ int bounded(unsigned m, unsigned mask) {
         if (m == 0) return 0;
         unsigned v;
@@ -129,20 +138,7 @@ struct Rng {
         } while (v > m);
         return (int)v;
     }
-
-    // RandomState.random(): (a * 2^26 + b) / 2^53 with a = w1 >> 5, b = w2 >> 6.
-    __device__ __forceinline__ double uniform() {
-        const uint32_t a = next() >> 5;
-        const uint32_t b = next() >> 6;
-        return ((double)a * 67108864.0 + (double)b) * 1.1102230246251565e-16;  // exact: * 2^-53
-    }
 };
-
-__device__ __forceinline__ unsigned mask_for(unsigned m) {
-    unsigned mask = m;
-    mask |= mask >> 1, mask |= mask >> 2, mask |= mask >> 4, mask |= mask >> 8, mask |= mask >> 16;
-    return mask;
-}
 
 // experiments.py:13-77, evaluation order kept, float64, no contraction.
 __device__ double beta_at(const KArgs& a, long long step) {
@@ -178,33 +174,18 @@ __device__ double beta_at(const KArgs& a, long long step) {
     }
 }
 
-// accept iff u < min(1, exp(x)), x = -beta * dE  (experiments.py:238-239, 326-327).
-// min(1.0, e) keeps 1.0 unless e < 1.0, so a NaN e accepts, like the reference.
-__device__ __forceinline__ bool accept_test(double x, double u, bool exact_only, int& ties) {
-    if (!(x < 0.0)) return true;  // e >= 1 (or NaN): probability 1, and u < 1 always
-    if (!exact_only) {
-        const float e32 = __expf((float)x);  // relative error < 2e-5 over the whole range
-        const double lo = (double)(e32 * 0.9990234375f), hi = (double)(e32 * 1.0009765625f);
-        if (u < lo) return true;
-        if (u > hi) return false;
-    }
-    const double e = exp(x);
-    if (e < 1.0) {
-        const long long d = __double_as_longlong(u) - __double_as_longlong(e);
-        if ((d < 0 ? -d : d) <= 4) ties++;
-        return u < e;
-    }
-    return true;
+__global__ __launch_bounds__(256) void mcq_beta_kernel(KArgs a) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (s < a.n_steps) a.beta_tab[s] = beta_at(a, s);
 }
 
-// sum over the G lanes of a group, result in every lane of the group
+// sum over the G lanes of a group (G = 8, 16 or 64), result in every lane of the group
 template <int G>
 __device__ __forceinline__ int group_sum(int v) {
-    // rotations inside a row of 16 lanes (DPP row_ror), then across rows
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);  // row_ror:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);  // row_ror:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);  // row_ror:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    if (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
     if (G >= 32) v += __shfl_xor(v, 16, 64);
     if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
@@ -240,8 +221,8 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
             s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)p + 1u;
         }
     }
-    Rng<64> rng;
-    rng.attach(mt, 0, 0, lane, 0);  // NumPy's pos == 624: the first draw starts a new generation
+    InitRng rng;
+    rng.mt = mt, rng.win = 0, rng.pos = 0, rng.gen_end = 0, rng.lane = lane;  // NumPy's pos == 624: the first draw starts a generation
 
     const unsigned mN = (unsigned)(N - 1);
     if (a.mode == MCQ_MODE_BOARD) {
@@ -335,26 +316,95 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sweep kernel: G lanes per chain, 64 / G chains per wavefront.
-// LDS per chain: mt[624] | board: heights bytes | full_3d: queens packed (i | j<<8 | k<<16) [Q], occupancy bits
+// sweep kernel
 // ------------------------------------------------------------------------------------------------
+// Per-chain stream state, replicated in the G lanes of the group.
+//   pos, gen   absolute counters of consumed / generated words; ring slot = counter & 63
+//   gi         MT index of the next block to generate (multiple of G, wraps at 624)
+//   okN        bit s set: the word in ring slot s passes (w & maskN) <= N-1
+template <int G>
+struct Stream {
+    uint32_t* mt;
+    uint32_t* ring;
+    uint32_t pos, gen;
+    int gi;
+    unsigned long long okN;
+    int gl, gshift;
+    unsigned maskN, mN;
+
+    __device__ __forceinline__ unsigned long long group_bits(bool pred) const {
+        return (__ballot(pred) >> gshift) & ((1ull << G) - 1);
+    }
+
+    // append G fresh words; the caller guarantees gen - pos <= RING - G
+    __device__ __forceinline__ void round() {
+        const int i = gi + gl;
+        const uint32_t v = mt_twist_word(mt, i);
+        mt[i] = v;
+        const uint32_t w = mt_temper(v);
+        const int so = gen & (RING - 1);
+        ring[so + gl] = w;
+        const unsigned long long bits = group_bits((w & maskN) <= mN);
+        okN = (okN & ~(((1ull << G) - 1) << so)) | (bits << so);
+        gen += G;
+        gi = gi + G == MT_N ? 0 : gi + G;
+    }
+
+    // continue the stream of a chain record: words [rpos, rge) of the current generation are
+    // already twisted but not consumed (fewer than 64 of them); temper them into the ring.
+    __device__ __forceinline__ void attach(uint32_t* lds_mt, uint32_t* lds_ring, int rpos, int rge, int gl_, int gshift_,
+                                           unsigned maskN_, unsigned mN_) {
+        mt = lds_mt, ring = lds_ring, gl = gl_, gshift = gshift_, maskN = maskN_, mN = mN_;
+        pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge, okN = 0;
+        for (int t0 = rpos & ~(G - 1); t0 < rge; t0 += G) {
+            const int t = t0 + gl;
+            const bool valid = t >= rpos && t < rge;
+            uint32_t w = 0;
+            if (valid) {
+                w = mt_temper(mt[t]);
+                ring[t & (RING - 1)] = w;
+            }
+            okN |= group_bits(valid && (w & maskN) <= mN) << (t0 & (RING - 1));
+        }
+    }
+};
+
+// exact accept test: u < min(1, exp(x)), x = -beta * dE in float64 (experiments.py:238-239, 326-327).
+// min(1.0, e) keeps 1.0 unless e < 1.0, so a NaN e accepts, like the reference.
+// Returns bit 0 = accepted, bit 1 = u within 4 ulp of the probability (a "near tie").
+__device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, uint32_t w2) {
+    const double x = -beta * (double)dE;
+    if (!(x < 0.0)) return 1;
+    const double u = ((double)(w1 >> 5) * 67108864.0 + (double)(w2 >> 6)) * 1.1102230246251565e-16;  // exact: * 2^-53
+    const double e = exp(x);
+    if (e < 1.0) {
+        const long long d = __double_as_longlong(u) - __double_as_longlong(e);
+        return (u < e ? 1 : 0) | ((d < 0 ? -d : d) <= 4 ? 2 : 0);
+    }
+    return 1;
+}
+
 constexpr int SWEEP_WAVES = 1;  // wavefronts per workgroup; chains never interact, so no barrier exists
 
+// LDS per chain: mt[624] | ring[64] | board: pad, heights bytes, pad | full_3d: queens packed (i | j<<8 | k<<16) [Q], occupancy bits
 template <int MODE, int G>
-__global__ __launch_bounds__(64 * SWEEP_WAVES) void mcq_sweep_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
+    constexpr int GEN_EVERY = G >= 16 ? 2 : 1;  // top the ring up every GEN_EVERY steps: the lanes of a wavefront refill together
+    constexpr int LAST = MODE == MCQ_MODE_BOARD ? 5 : 6;  // sequential-draw stages of one proposal
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gl = lane & (G - 1), grp = lane / G, gbase = lane - gl;
+    const int gl = lane & (G - 1), grp = lane / G;
     const long long chain = ((long long)blockIdx.x * SWEEP_WAVES + wave) * CPW + grp;
     const int N = a.N, Q = a.Q;
     bool active = chain < a.n_chains;
     const long long crow = active ? chain : 0;
 
     uint32_t* mt = lds + (wave * CPW + grp) * a.chain_lds_words;
-    uint8_t* hts = (uint8_t*)(mt + MT_N);             // board
-    uint32_t* qn = mt + MT_N;                          // full_3d: packed queens
-    uint32_t* occ = qn + Q;                            // full_3d: N^3 occupancy bits
+    uint32_t* ring = mt + MT_N;
+    uint8_t* hts = (uint8_t*)(ring + RING + 8);  // board (the diagonal probes read up to N-1 bytes outside either end)
+    uint32_t* qn = ring + RING;                  // full_3d: packed queens
+    uint32_t* occ = qn + Q;                      // full_3d: N^3 occupancy bits
 
     // ---- load the chain record ----
     const uint32_t* rec = a.ws + crow * (long long)a.rec_words;
@@ -371,129 +421,235 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void mcq_sweep_kernel(KArgs a) {
             atomicOr(&occ[f >> 5], 1u << (f & 31));
         }
     }
-    Rng<G> rng;
-    rng.attach(mt, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, gbase);
+    const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
+    const unsigned maskN = a.maskN, maskQ = a.maskQ;
+    Stream<G> rng;
+    rng.attach(mt, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, grp * G, maskN, mN);
 
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
-    long long hist_len = a.n_steps + 1, executed = a.n_steps;
-    unsigned long long accw = 0;
-    int hv = E;  // lane gl stages history entry (block base + gl); entry 0 = E0
+    int hist_len = (int)a.n_steps + 1;
+    uint32_t accw = 0;  // accept bits of the current block of 32 steps
+    int hv = E;         // lane gl stages history entry (block base + gl); entry 0 = E0
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
+    const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
     const bool trace = a.out.energy_hist != nullptr;
-    int32_t* hist = trace ? a.out.energy_hist + crow * a.hist_stride : nullptr;
-    unsigned long long* bits = a.out.accept_bits ? (unsigned long long*)a.out.accept_bits + crow * a.bits_stride : nullptr;
-    uint8_t* best_out = a.out.best_state ? a.out.best_state + crow * (long long)a.state_bytes : nullptr;
-    const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
+    int32_t* hist = trace ? a.out.energy_hist + crow * a.hist_stride + gl : nullptr;
+    uint32_t* bits = a.out.accept_bits ? (uint32_t*)a.out.accept_bits + crow * a.bits_stride * 2 : nullptr;
+    const int patience = a.patience < 0 ? 0x7fffffff : (a.patience > 0x7fffffff ? 0x7fffffff : (int)a.patience);
+    const bool has_patience = MODE == MCQ_MODE_BOARD && a.patience >= 0;
 
     if (active) {
         if (gl == 0 && a.out.initial_energy) a.out.initial_energy[chain] = E;
-        if (best_out)
-            for (int c = gl; c < a.state_bytes; c += G) best_out[c] = rst[c];
+        if (a.out.best_state) {
+            uint8_t* bo = a.out.best_state + crow * (long long)a.state_bytes;
+            for (int c = gl; c < a.state_bytes; c += G) bo[c] = rst[c];
+        }
     }
 
-    double bvec = 0.0;  // lane L: beta(step0 + L) for the current block of 64 steps
     const int n_steps = (int)a.n_steps;
     for (int step = 0; step < n_steps; step++) {
-        if ((step & 63) == 0) bvec = beta_at(a, (long long)step + lane);
-        const int bsel = step & 63;
-        const double beta = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bvec), bsel),
-                                             __builtin_amdgcn_readlane(__double2loint(bvec), bsel));
+        // ---- wave-uniform per-step values (scalar loads / scalar ALU) ----
+        const double beta = a.beta_tab[step];
+        const bool bpos = beta > 0.0, bneg = beta < 0.0;
+        const float c32 = (float)(-beta * 1.4426950408889634);  // exp(-beta dE) = exp2(dE * c32)
+
         if (active) {
+            // ---- proposal draws -----------------------------------------------------------------
+            // board   (experiments.py:311-327): i, j, new_k (redrawn while == old_k), then random()
+            // full_3d (experiments.py:221-239): q, (i, j, k) redrawn while the cell is occupied, random()
+            int pa = 0, pb = 0, pc = 0;  // board: i, j, new_k      full_3d: ni, nj, nk
+            int cell = 0, old_k = 0;     // board
+            int qi = 0;                  // full_3d
+            uint32_t oldp = 0;
+            uint32_t uw1 = 0, uw2 = 0;   // the two words of random()
+            int stage = 0;
+            bool topup = (step % GEN_EVERY) == 0;
+            for (;;) {
+                if (topup)
+                    while (rng.gen - rng.pos <= (uint32_t)(RING - G)) rng.round();
+                topup = true;  // a second pass means the ring ran dry
+                if (MODE == MCQ_MODE_BOARD && stage == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
+                    // positions of the next four accepted words inside the 32 ring slots that follow pos
+                    const int s = rng.pos & (RING - 1);
+                    const uint32_t lo = (uint32_t)rng.okN, hi = (uint32_t)(rng.okN >> 32);
+                    uint32_t v = __builtin_amdgcn_alignbit((s & 32) ? lo : hi, (s & 32) ? hi : lo, (uint32_t)s & 31u);
+                    const uint32_t p1 = (uint32_t)__ffs(v) - 1u;
+                    v &= v - 1;
+                    const uint32_t p2 = (uint32_t)__ffs(v) - 1u;
+                    v &= v - 1;
+                    const uint32_t p3 = (uint32_t)__ffs(v) - 1u;
+                    v &= v - 1;
+                    const uint32_t p4 = (uint32_t)__ffs(v) - 1u;
+                    if (p4 <= 29u) {  // four accepted words, and the two words of the uniform still inside the view
+                        const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)];
+                        const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)];
+                        pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
+                        const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN);
+                        cell = pa * N + pb;
+                        old_k = hts[cell];
+                        const bool use3 = c3 != old_k;
+                        pc = use3 ? c3 : c4;
+                        if (use3 || c4 != old_k) {
+                            const uint32_t kp = use3 ? p3 : p4;
+                            uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
+                            rng.pos += kp + 3;
+                            break;
+                        }
+                    }
+                }
+                // sequential: one word at a time from what the ring holds (nothing was consumed above)
+                while (rng.pos != rng.gen && stage < LAST) {
+                    const uint32_t w = ring[rng.pos & (RING - 1)];
+                    rng.pos++;
+                    const int vN = (int)(w & maskN);
+                    const bool okN = (unsigned)vN <= mN;
+                    if (MODE == MCQ_MODE_BOARD) {
+                        if (stage == 0) {
+                            if (okN) pa = vN, stage = 1;
+                        } else if (stage == 1) {
+                            if (okN) pb = vN, cell = pa * N + pb, old_k = hts[cell], stage = 2;
+                        } else if (stage == 2) {
+                            if (okN && vN != old_k) pc = vN, stage = 3;
+                        } else if (stage == 3) {
+                            uw1 = w, stage = 4;
+                        } else {
+                            uw2 = w, stage = 5;
+                        }
+                    } else {
+                        if (stage == 0) {
+                            const unsigned vQ = w & maskQ;
+                            if (vQ <= mQ) qi = (int)vQ, oldp = qn[qi], stage = 1;
+                        } else if (stage == 1) {
+                            if (okN) pa = vN, stage = 2;
+                        } else if (stage == 2) {
+                            if (okN) pb = vN, stage = 3;
+                        } else if (stage == 3) {
+                            if (okN) {
+                                pc = vN;
+                                const int f = (pa * N + pb) * N + pc;
+                                stage = ((occ[f >> 5] >> (f & 31)) & 1u) ? 1 : 4;  // occupied: draw the triple again
+                            }
+                        } else if (stage == 4) {
+                            uw1 = w, stage = 5;
+                        } else {
+                            uw2 = w, stage = 6;
+                        }
+                    }
+                }
+                if (stage == LAST) break;
+            }
+
+            // ---- dE -------------------------------------------------------------------------------
             int dE;
-            int cell = 0, new_k = 0;          // board move
-            int qi = 0;                       // full_3d move
-            uint32_t oldp = 0, newp = 0;
+            uint32_t newp = 0;
             if (MODE == MCQ_MODE_BOARD) {
-                // experiments.py:311-321
-                const int i = rng.bounded(mN, a.maskN);
-                const int j = rng.bounded(mN, a.maskN);
-                cell = i * N + j;
-                const int old_k = hts[cell];
-                do {
-                    new_k = rng.bounded(mN, a.maskN);
-                } while (new_k == old_k);
-                // conflicts(new_k) - conflicts(old_k) over the <= 4N columns that share a line of the
-                // ij-plane with (i, j): row, column, diagonal, anti-diagonal (mcmc_board.py:177-191).
+                // dE = conflicts(new_k) - conflicts(old_k) (mcmc_board.py:147-193).  Probe the columns on the
+                // four lines of the ij-plane through (i, j).  Column (i2, j2) at distance d holds height h; it
+                // attacks (i, j, k) iff h - k is 0 or +-d.  The cell (i, j) itself is probed once per direction
+                // and always scores -1 (it holds old_k): +4 below.
+                const int i = pa, j = pb;
+                const uint32_t Bo = 1u << old_k, Bn = 1u << pc;
                 int part = 0;
-                for (int p = gl; p < 4 * N; p += G) {
-                    const int dir = (p >= N) + (p >= 2 * N) + (p >= 3 * N);
-                    const int m = p - dir * N;
-                    const int i2 = dir == 0 ? i : m;
-                    const int j2 = dir == 0 ? m : dir == 1 ? j : dir == 2 ? m - i + j : i + j - m;
-                    const bool ok = (unsigned)j2 < (unsigned)N && !(i2 == i && j2 == j);
-                    const int d = max(abs(i2 - i), abs(j2 - j));
-                    const int h = hts[ok ? i2 * N + j2 : 0];
-                    const int ao = abs(h - old_k), an = abs(h - new_k);
-                    const int c = (int)(an == 0 || an == d) - (int)(ao == 0 || ao == d);
-                    part += ok ? c : 0;
+#pragma unroll 1
+                for (int m = gl; m < N; m += G) {
+                    {  // row i: column (i, m)
+                        const uint32_t d = (uint32_t)abs(m - j);
+                        const uint32_t h = hts[i * N + m];
+                        const uint32_t Mo = Bo | (Bo << d) | (Bo >> d), Mn = Bn | (Bn << d) | (Bn >> d);
+                        part += (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
+                    }
+                    const uint32_t d = (uint32_t)abs(m - i);
+                    const uint32_t Mo = Bo | (Bo << d) | (Bo >> d), Mn = Bn | (Bn << d) | (Bn >> d);
+                    {  // column j: (m, j)
+                        const uint32_t h = hts[m * N + j];
+                        part += (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
+                    }
+                    {  // diagonal: (m, m - i + j)
+                        const int j2 = m - i + j;
+                        const uint32_t h = hts[m * N + j2] & 31u;  // out-of-board reads stay inside the chain's LDS and are discarded
+                        const int c = (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
+                        part += (unsigned)j2 < (unsigned)N ? c : 0;
+                    }
+                    {  // anti-diagonal: (m, i + j - m)
+                        const int j2 = i + j - m;
+                        const uint32_t h = hts[m * N + j2] & 31u;
+                        const int c = (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
+                        part += (unsigned)j2 < (unsigned)N ? c : 0;
+                    }
                 }
-                dE = group_sum<G>(part);
+                dE = group_sum<G>(part) + 4;
             } else {
-                // experiments.py:221-235
-                qi = rng.bounded(mQ, a.maskQ);
-                oldp = qn[qi];
-                int ni, nj, nk;
-                for (;;) {
-                    ni = rng.bounded(mN, a.maskN);
-                    nj = rng.bounded(mN, a.maskN);
-                    nk = rng.bounded(mN, a.maskN);
-                    const int f = (ni * N + nj) * N + nk;
-                    if (!((occ[f >> 5] >> (f & 31)) & 1u)) break;
-                }
+                // every other queen against the old and the new cell (mcmc.py:185-226)
+                const int ni = pa, nj = pb, nk = pc;
                 newp = (uint32_t)ni | ((uint32_t)nj << 8) | ((uint32_t)nk << 16);
                 const int oi = oldp & 255, oj = (oldp >> 8) & 255, ok_ = (oldp >> 16) & 255;
                 int part = 0;
-                for (int c = gl; c < Q; c += G) {  // every other queen against both cells (mcmc.py:185-226)
-                    const uint32_t pc = qn[c];
-                    const int ci = pc & 255, cj = (pc >> 8) & 255, ck = (pc >> 16) & 255;
+#pragma unroll 1
+                for (int c = gl; c < Q; c += G) {
+                    const uint32_t pq = qn[c];
+                    const int ci = pq & 255, cj = (pq >> 8) & 255, ck = (pq >> 16) & 255;
                     const int v = (int)on_a_line(ci - ni, cj - nj, ck - nk) - (int)on_a_line(ci - oi, cj - oj, ck - ok_);
                     part += c != qi ? v : 0;
                 }
                 dE = group_sum<G>(part);
             }
 
-            const double u = rng.uniform();
-            const bool acc = accept_test(-beta * (double)dE, u, exact_only, ties);
+            // ---- accept iff u < min(1, exp(-beta dE)); the uniform is always drawn -------------------
+            const bool xneg = (bpos && dE > 0) || (bneg && dE < 0);  // x = -beta dE < 0; otherwise probability 1
+            bool acc = !xneg, exact = xneg;
+            if (!exact_only) {
+                // u * 2^27 lies in [a27, a27 + 1); e27 = exp(x) * 2^27 within 3e-5 relative
+                const float fa = (float)(uw1 >> 5);
+                const float e27 = __builtin_amdgcn_exp2f(fmaf((float)dE, c32, 27.0f));
+                const bool sure_acc = fa + 1.0f < e27 * 0.9990234375f;
+                const bool sure_rej = fa > e27 * 1.0009765625f;
+                acc = acc || sure_acc;
+                exact = xneg && !sure_acc && !sure_rej;
+            }
+            if (exact) {
+                const int r = accept_exact(beta, dE, uw1, uw2);
+                acc = (r & 1) != 0, ties += r >> 1;
+            }
+
             bool improved = false;
             if (acc) {
-                accw |= 1ull << (step & 63);
+                accw |= 1u << (step & 31);
                 if (MODE == MCQ_MODE_BOARD) {
-                    if (gl == 0) hts[cell] = (uint8_t)new_k;
+                    if (gl == 0) hts[cell] = (uint8_t)pc;
                 } else if (gl == 0) {
                     const int fo = ((int)(oldp & 255) * N + (int)((oldp >> 8) & 255)) * N + (int)((oldp >> 16) & 255);
-                    const int fn = ((int)(newp & 255) * N + (int)((newp >> 8) & 255)) * N + (int)((newp >> 16) & 255);
+                    const int fn = (pa * N + pb) * N + pc;
                     occ[fo >> 5] &= ~(1u << (fo & 31));
                     occ[fn >> 5] |= 1u << (fn & 31);
                     qn[qi] = newp;
                 }
                 E += dE;
                 n_acc++;
-                if (E < best) {
-                    best = E, no_imp = 0, improved = true;
-                    if (best_out) {
-                        if (MODE == MCQ_MODE_BOARD) {
-                            for (int c = gl; c < Q; c += G) best_out[c] = hts[c];
-                        } else {
-                            for (int c = gl; c < Q; c += G) {
-                                const uint32_t pc = qn[c];
-                                best_out[3 * c] = (uint8_t)pc, best_out[3 * c + 1] = (uint8_t)(pc >> 8), best_out[3 * c + 2] = (uint8_t)(pc >> 16);
-                            }
+                improved = E < best;
+            }
+            no_imp = improved ? 0 : no_imp + 1;
+            if (improved) {
+                best = E;
+                if (a.out.best_state) {
+                    uint8_t* bo = a.out.best_state + chain * (long long)a.state_bytes;
+                    if (MODE == MCQ_MODE_BOARD) {
+                        for (int c = gl; c < Q; c += G) bo[c] = hts[c];
+                    } else {
+                        for (int c = gl; c < Q; c += G) {
+                            const uint32_t pq = qn[c];
+                            bo[3 * c] = (uint8_t)pq, bo[3 * c + 1] = (uint8_t)(pq >> 8), bo[3 * c + 2] = (uint8_t)(pq >> 16);
                         }
                     }
-                } else {
-                    no_imp++;
                 }
-            } else {
-                no_imp++;
             }
 
-            if (MODE == MCQ_MODE_BOARD && a.patience >= 0 && no_imp >= a.patience) {
+            if (has_patience && no_imp >= patience) {
                 // break BEFORE the append (experiments.py:349-353): entries 0..step are valid
                 active = false;
-                hist_len = step + 1, executed = step + 1;
-                if (trace && gl <= (step & (G - 1))) hist[(step & ~(G - 1)) + gl] = hv;
-                if (bits && gl == 0) bits[step >> 6] = accw;
+                hist_len = step + 1;
+                if (trace && gl <= (step & (G - 1))) hist[step & ~(G - 1)] = hv;
+                if (bits && gl == 0) bits[step >> 5] = accw;
             } else {
                 const int e = step + 1;
                 if ((e & (G - 1)) == gl) hv = E;
@@ -501,22 +657,22 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void mcq_sweep_kernel(KArgs a) {
             }
         }
         const int e = step + 1;
-        if ((e & (G - 1)) == G - 1 && trace && active) hist[e - (G - 1) + gl] = hv;
-        if ((step & 63) == 63) {
-            if (bits && active && gl == 0) bits[step >> 6] = accw;
+        if ((e & (G - 1)) == G - 1 && trace && active) hist[e - (G - 1)] = hv;
+        if ((step & 31) == 31) {
+            if (bits && active && gl == 0) bits[step >> 5] = accw;
             accw = 0;
         }
-        if (!__any(active)) break;
+        if (has_patience && !__any(active)) break;
     }
 
     if (active) {  // ran to n_steps: flush the partial last block and word
-        if (trace && (n_steps & (G - 1)) != G - 1 && gl <= (n_steps & (G - 1))) hist[(n_steps & ~(G - 1)) + gl] = hv;
-        if (bits && gl == 0 && (n_steps & 63) != 0) bits[n_steps >> 6] = accw;
+        if (trace && (n_steps & (G - 1)) != G - 1 && gl <= (n_steps & (G - 1))) hist[n_steps & ~(G - 1)] = hv;
+        if (bits && gl == 0 && (n_steps & 31) != 0) bits[n_steps >> 5] = accw;
     }
     if (chain < a.n_chains) {
         if (gl == 0) {
             if (a.out.hist_len) a.out.hist_len[chain] = hist_len;
-            if (a.out.steps_executed) a.out.steps_executed[chain] = executed;
+            if (a.out.steps_executed) a.out.steps_executed[chain] = hist_len == n_steps + 1 ? n_steps : hist_len;
             if (a.out.best_energy) a.out.best_energy[chain] = best;
             if (a.out.final_energy) a.out.final_energy[chain] = E;
             if (a.out.steps_to_best) a.out.steps_to_best[chain] = best_step;
@@ -529,8 +685,8 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void mcq_sweep_kernel(KArgs a) {
                 for (int c = gl; c < Q; c += G) fo[c] = hts[c];
             } else {
                 for (int c = gl; c < Q; c += G) {
-                    const uint32_t pc = qn[c];
-                    fo[3 * c] = (uint8_t)pc, fo[3 * c + 1] = (uint8_t)(pc >> 8), fo[3 * c + 2] = (uint8_t)(pc >> 16);
+                    const uint32_t pq = qn[c];
+                    fo[3 * c] = (uint8_t)pq, fo[3 * c + 1] = (uint8_t)(pq >> 8), fo[3 * c + 2] = (uint8_t)(pq >> 16);
                 }
             }
         }
@@ -547,9 +703,9 @@ int fail(int code, const char* fmt, const char* detail = "") {
     return code;
 }
 
-#define HIP_TRY(expr)                                                              \
-    do {                                                                           \
-        hipError_t e_ = (expr);                                                    \
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) return fail(MCQ_EDEVICE, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
@@ -578,12 +734,14 @@ int validate(const mcq_params* p) {
     if (p->trace != MCQ_TRACE_NONE && p->trace != MCQ_TRACE_I32) return fail(MCQ_EINVAL, "unknown trace mode");
     if (p->n_steps < 0 || p->n_steps > 2147483000LL) return fail(MCQ_EINVAL, "n_steps out of range [0, 2^31)");
     if (p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_chains");
-    if (p->lanes_per_chain != 0 && p->lanes_per_chain != 16 && p->lanes_per_chain != 32 && p->lanes_per_chain != 64)
-        return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 16, 32 or 64");
+    if (p->lanes_per_chain != 0 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
+        return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 8 or 16");
     return MCQ_OK;
 }
 
 int rec_words_for(const mcq_params* p) { return REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4); }
+
+size_t beta_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 8 + 255) & ~(size_t)255; }
 
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
     memset(a, 0, sizeof *a);
@@ -600,12 +758,16 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     }
     a->state_bytes = (int)mcq_state_bytes(p->N, p->mode);
     a->rec_words = rec_words_for(p);
-    a->chain_lds_words = MT_N + (p->mode == MCQ_MODE_BOARD ? (a->Q + 3) / 4 : a->Q + (p->N * p->N * p->N + 31) / 32);
+    // board: the diagonal probes read up to N-1 bytes before / after the heights; 8 spare words on each
+    // side keep those (discarded) reads inside the chain's own LDS slice.
+    a->chain_lds_words = MT_N + RING + (p->mode == MCQ_MODE_BOARD ? 8 + (a->Q + 3) / 4 + 8 : a->Q + (p->N * p->N * p->N + 31) / 32);
     a->beta_const = p->beta_const, a->beta_start = p->beta_start, a->beta_end = p->beta_end;
     a->n_steps = p->n_steps, a->n_chains = p->n_chains;
     a->patience = p->mode == MCQ_MODE_BOARD ? p->patience : -1;  // full_3d ignores early_stop_patience (experiments.py:199-279)
     a->hist_stride = p->hist_stride, a->bits_stride = p->bits_stride;
-    a->ws = (uint32_t*)ws, a->seeds = seeds, a->out = *out;
+    a->beta_tab = (double*)ws;
+    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p));
+    a->seeds = seeds, a->out = *out;
     if (p->trace == MCQ_TRACE_NONE) a->out.energy_hist = nullptr, a->out.accept_bits = nullptr;
     return MCQ_OK;
 }
@@ -619,6 +781,47 @@ int launch_sweep(const KArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
     hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G>), dim3(grid), dim3(64 * SWEEP_WAVES), lds, s, a);
     HIP_TRY(hipGetLastError());
+    return MCQ_OK;
+}
+
+int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
+                    size_t workspace_bytes, void* hip_stream, hipEvent_t* ev) {
+    int rc = validate(p);
+    if (rc != MCQ_OK) return rc;
+    if (!seeds || !out || !workspace) return fail(MCQ_EINVAL, "null argument");
+    if (workspace_bytes < mcq_workspace_bytes(p)) return fail(MCQ_ENOMEM, "workspace too small");
+    if (p->trace == MCQ_TRACE_I32) {
+        if (!out->energy_hist || !out->accept_bits) return fail(MCQ_EINVAL, "trace requested without buffers");
+        if (p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
+        if (p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (p->n_chains == 0) {
+        if (ev)
+            for (int t = 0; t < 3; t++) HIP_TRY(hipEventRecord(ev[t], s));
+        return MCQ_OK;
+    }
+    KArgs a;
+    rc = build_args(p, seeds, out, workspace, &a);
+    if (rc != MCQ_OK) return rc;
+
+    if (a.out.accept_bits)  // chains that stop early leave their later words untouched
+        HIP_TRY(hipMemsetAsync(a.out.accept_bits, 0, (size_t)p->n_chains * p->bits_stride * 8, s));
+
+    size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
+    if (p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM) init_lds += (size_t)p->N * p->N * p->N * 2;
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
+    if (p->n_steps > 0) hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
+    HIP_TRY(hipGetLastError());
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+
+    const int G = p->lanes_per_chain ? p->lanes_per_chain : 16;
+    if (p->mode == MCQ_MODE_BOARD) rc = G == 8 ? launch_sweep<MCQ_MODE_BOARD, 8>(a, s) : launch_sweep<MCQ_MODE_BOARD, 16>(a, s);
+    else rc = G == 8 ? launch_sweep<MCQ_MODE_FULL3D, 8>(a, s) : launch_sweep<MCQ_MODE_FULL3D, 16>(a, s);
+    if (rc != MCQ_OK) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     return MCQ_OK;
 }
 
@@ -643,53 +846,7 @@ size_t mcq_state_bytes(int32_t N, int32_t mode) {
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
-    return (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
-}
-
-static int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
-                           size_t workspace_bytes, void* hip_stream, hipEvent_t* ev) {
-    int rc = validate(p);
-    if (rc != MCQ_OK) return rc;
-    if (!seeds || !out || !workspace) return fail(MCQ_EINVAL, "null argument");
-    if (workspace_bytes < mcq_workspace_bytes(p)) return fail(MCQ_ENOMEM, "workspace too small");
-    if (p->trace == MCQ_TRACE_I32) {
-        if (!out->energy_hist || !out->accept_bits) return fail(MCQ_EINVAL, "trace requested without buffers");
-        if (p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
-        if (p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
-    }
-    if (p->n_chains == 0) {
-        if (ev) for (int t = 0; t < 3; t++) HIP_TRY(hipEventRecord(ev[t], (hipStream_t)hip_stream));
-        return MCQ_OK;
-    }
-    KArgs a;
-    rc = build_args(p, seeds, out, workspace, &a);
-    if (rc != MCQ_OK) return rc;
-    hipStream_t s = (hipStream_t)hip_stream;
-
-    if (a.out.accept_bits)  // chains that stop early leave their later words untouched
-        HIP_TRY(hipMemsetAsync(a.out.accept_bits, 0, (size_t)p->n_chains * p->bits_stride * 8, s));
-
-    size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
-    if (p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM) init_lds += (size_t)p->N * p->N * p->N * 2;
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
-    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
-    HIP_TRY(hipGetLastError());
-    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-
-    const int G = p->lanes_per_chain ? p->lanes_per_chain : 16;
-    if (p->mode == MCQ_MODE_BOARD) {
-        if (G == 16) rc = launch_sweep<MCQ_MODE_BOARD, 16>(a, s);
-        else if (G == 32) rc = launch_sweep<MCQ_MODE_BOARD, 32>(a, s);
-        else rc = launch_sweep<MCQ_MODE_BOARD, 64>(a, s);
-    } else {
-        if (G == 16) rc = launch_sweep<MCQ_MODE_FULL3D, 16>(a, s);
-        else if (G == 32) rc = launch_sweep<MCQ_MODE_FULL3D, 32>(a, s);
-        else rc = launch_sweep<MCQ_MODE_FULL3D, 64>(a, s);
-    }
-    if (rc != MCQ_OK) return rc;
-    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
-    return MCQ_OK;
+    return beta_tab_bytes(p) + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -703,7 +860,7 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     int rc = run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, ev);
     float a = 0.f, b = 0.f;
-    if (rc == MCQ_OK && p->n_chains > 0) {
+    if (rc == MCQ_OK) {
         hipError_t e = hipEventSynchronize(ev[2]);
         if (e == hipSuccess) e = hipEventElapsedTime(&a, ev[0], ev[1]);
         if (e == hipSuccess) e = hipEventElapsedTime(&b, ev[1], ev[2]);
@@ -748,43 +905,33 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
     };
     uint32_t* d_seeds = nullptr;
     void* d_ws = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     const size_t ws_bytes = mcq_workspace_bytes(p);
-    rc = MCQ_OK;
     auto cleanup = [&]() {
         for (auto& b : bufs)
             if (*b.dev) (void)hipFree(*b.dev);
         if (d_seeds) (void)hipFree(d_seeds);
         if (d_ws) (void)hipFree(d_ws);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
     };
-#define HOST_TRY(expr)                                                                \
-    do {                                                                              \
-        hipError_t e_ = (expr);                                                       \
-        if (e_ != hipSuccess) {                                                       \
-            cleanup();                                                                \
+#define HOST_TRY(expr)                                                                                              \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if (e_ != hipSuccess) {                                                                                     \
+            cleanup();                                                                                              \
             return fail(e_ == hipErrorOutOfMemory ? MCQ_ENOMEM : MCQ_EDEVICE, #expr ": %s", hipGetErrorString(e_)); \
-        }                                                                             \
+        }                                                                                                           \
     } while (0)
     for (auto& b : bufs)
         if (b.host) HOST_TRY(hipMalloc(b.dev, b.bytes));
     HOST_TRY(hipMalloc((void**)&d_seeds, n * 4));
     HOST_TRY(hipMalloc(&d_ws, ws_bytes));
     HOST_TRY(hipMemcpy(d_seeds, seeds, n * 4, hipMemcpyHostToDevice));
-    HOST_TRY(hipEventCreate(&e0));
-    HOST_TRY(hipEventCreate(&e1));
-    HOST_TRY(hipEventRecord(e0, nullptr));
-    rc = mcq_run_device(p, d_seeds, &d, d_ws, ws_bytes, nullptr);
+    float i_ms = 0.f, s_ms = 0.f;
+    rc = mcq_run_device_timed(p, d_seeds, &d, d_ws, ws_bytes, nullptr, &i_ms, &s_ms);
     if (rc != MCQ_OK) {
         cleanup();
         return rc;
     }
-    HOST_TRY(hipEventRecord(e1, nullptr));
-    HOST_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HOST_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (kernel_seconds) *kernel_seconds = ms * 1e-3;
+    if (kernel_seconds) *kernel_seconds = (i_ms + s_ms) * 1e-3;
     for (auto& b : bufs)
         if (b.host) HOST_TRY(hipMemcpy(b.host, *b.dev, b.bytes, hipMemcpyDeviceToHost));
     cleanup();

@@ -13,7 +13,7 @@ from tests import util
 
 abi = mcq_amd.abi
 pytestmark = pytest.mark.gpu
-LANES = (16, 32, 64)
+LANES = (8, 16)
 
 
 def _group_key(c):
@@ -70,6 +70,18 @@ def test_exact_exp_flag_changes_nothing():
         a, _ = mcq_amd._lib.run_host(abi.make_params(9, 4000, "random", sp, 96, mcmc_type=mode), seeds)
         b, _ = mcq_amd._lib.run_host(abi.make_params(9, 4000, "random", sp, 96, mcmc_type=mode, flags=abi.FLAG_EXACT_EXP), seeds)
         util.assert_results_equal(a, b, f"bracketed vs exact exp ({mode})")
+
+
+def test_sequential_draw_flag_changes_nothing():
+    """The batched proposal (accept-bit selection from the ring) equals word-by-word drawing."""
+    sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}
+    seeds = abi.seeds_for(2024, 128)
+    for N in (3, 12, 17):
+        for lanes in LANES:
+            a, _ = mcq_amd._lib.run_host(abi.make_params(N, 3000, "random", sp, 128, mcmc_type="board", lanes_per_chain=lanes), seeds)
+            b, _ = mcq_amd._lib.run_host(abi.make_params(N, 3000, "random", sp, 128, mcmc_type="board", lanes_per_chain=lanes,
+                                                         flags=abi.FLAG_SEQUENTIAL_DRAWS), seeds)
+            util.assert_results_equal(a, b, f"batched vs sequential draws N={N} G={lanes}")
 
 
 def test_trace_none_matches_trace_i32():
