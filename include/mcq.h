@@ -87,7 +87,7 @@ typedef struct mcq_params {
     int64_t patience;        /* early_stop_patience, board only (experiments.py:349-353); < 0 = None */
     int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1 */
     int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
-    int32_t lanes_per_chain; /* HIP only: 8 or 16 lanes of a wavefront per chain; 0 = library default */
+    int32_t lanes_per_chain; /* HIP only: 4, 8 or 16 lanes of a wavefront per chain; 0 = library default */
     int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
 } mcq_params;
 

@@ -68,6 +68,7 @@ struct KArgs {
     long long n_steps, n_chains, patience, hist_stride, bits_stride;
     uint32_t* ws;           // chain records
     double* beta_tab;       // [n_steps] beta(step), filled by mcq_beta_kernel
+    float* c32_tab;         // [n_steps] (float)(-beta(step) * log2(e)): exp(-beta dE) = exp2(dE * c32)
     const uint32_t* seeds;
     mcq_outputs out;
 };
@@ -176,18 +177,16 @@ __device__ double beta_at(const KArgs& a, long long step) {
 
 __global__ __launch_bounds__(256) void mcq_beta_kernel(KArgs a) {
     const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (s < a.n_steps) a.beta_tab[s] = beta_at(a, s);
+    if (s < a.n_steps) {
+        const double b = beta_at(a, s);
+        a.beta_tab[s] = b;
+        a.c32_tab[s] = (float)(-b * 1.4426950408889634);
+    }
 }
 
-// sum over the G lanes of a group (G = 8, 16 or 64), result in every lane of the group
-template <int G>
-__device__ __forceinline__ int group_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
-    if (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
-    if (G >= 32) v += __shfl_xor(v, 16, 64);
-    if (G >= 64) v += __shfl_xor(v, 32, 64);
+// sum over the 64 lanes of a wavefront, result in every lane
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
             e += on_a_line(xi - yi, xj - yj, xk - yk) ? 1 : 0;
         }
     }
-    e = group_sum<64>(e);
+    e = wave_sum(e);
 
     uint32_t* rec = a.ws + chain * (long long)a.rec_words;
     for (int w = lane; w < MT_N; w += 64) rec[w] = mt[w];
@@ -318,53 +317,122 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
 // ------------------------------------------------------------------------------------------------
 // sweep kernel
 // ------------------------------------------------------------------------------------------------
+// DPP reductions over the G lanes of a group (G = 4, 8 or 16), result in every lane of the group.
+template <int G>
+__device__ __forceinline__ int group_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);                // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);                // quad_perm [2,3,0,1]
+    if (G >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    if (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_or(uint32_t u) {
+    int v = (int)u;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    if (G >= 8) v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    if (G >= 16) v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return (uint32_t)v;
+}
+
 // Per-chain stream state, replicated in the G lanes of the group.
+//
+// The 624 raw MT19937 words of a chain stay in its record in GLOBAL memory (2.5 KB per chain would
+// cap a CU at ~56 chains if they lived in LDS).  They are regenerated in blocks of 16 words, 16/G
+// words per lane: the block's inputs are loaded (`issue`) two Metropolis steps before they are
+// consumed (`complete`), so the memory latency is covered by the steps in between; `complete`
+// twists, writes the new raw words back in place, tempers them and appends them to a 64-slot ring
+// of ready words in LDS together with one accept bit per slot ((w & maskN) <= N-1, the masked
+// rejection test of randint(0, N)).
 //   pos, gen   absolute counters of consumed / generated words; ring slot = counter & 63
-//   gi         MT index of the next block to generate (multiple of G, wraps at 624)
-//   okN        bit s set: the word in ring slot s passes (w & maskN) <= N-1
+//   gi         MT index of the next block to generate (multiple of 16, wraps at 624)
 template <int G>
 struct Stream {
-    uint32_t* mt;
+    static constexpr int WPL = 16 / G;  // words per lane in a block
+    uint32_t* g_mt;
     uint32_t* ring;
     uint32_t pos, gen;
     int gi;
-    unsigned long long okN;
-    int gl, gshift;
+    uint32_t ok_lo, ok_hi;
+    bool pending;
+    uint32_t pa[WPL], pn, px[WPL];
+    int gl;
     unsigned maskN, mN;
 
-    __device__ __forceinline__ unsigned long long group_bits(bool pred) const {
-        return (__ballot(pred) >> gshift) & ((1ull << G) - 1);
+    __device__ __forceinline__ void set_field(int so, uint32_t bits16) {
+        const uint32_t sh = (uint32_t)so & 16u;
+        const uint32_t half = (so & 32) ? ok_hi : ok_lo;
+        const uint32_t upd = (half & ~(0xFFFFu << sh)) | (bits16 << sh);
+        ok_lo = (so & 32) ? ok_lo : upd;
+        ok_hi = (so & 32) ? upd : ok_hi;
     }
 
-    // append G fresh words; the caller guarantees gen - pos <= RING - G
-    __device__ __forceinline__ void round() {
-        const int i = gi + gl;
-        const uint32_t v = mt_twist_word(mt, i);
-        mt[i] = v;
-        const uint32_t w = mt_temper(v);
+    // load the inputs of block gi: words i, i+1 and (i+397) mod 624 for the lane's WPL words
+    __device__ __forceinline__ void issue() {
+        const int i0 = gi + gl * WPL;
+        if constexpr (WPL == 4) {
+            const uint4 q = *(const uint4*)(g_mt + i0);
+            pa[0] = q.x, pa[1] = q.y, pa[2] = q.z, pa[3] = q.w;
+        } else if constexpr (WPL == 2) {
+            const uint2 q = *(const uint2*)(g_mt + i0);
+            pa[0] = q.x, pa[1] = q.y;
+        } else {
+            pa[0] = g_mt[i0];
+        }
+        const int in = i0 + WPL;
+        pn = g_mt[in == MT_N ? 0 : in];  // word 623 pairs with the NEW word 0, already written back
+#pragma unroll
+        for (int w = 0; w < WPL; w++) {
+            const int ix = i0 + w + MT_M;
+            px[w] = g_mt[ix >= MT_N ? ix - MT_N : ix];
+        }
+        pending = true;
+    }
+
+    // twist + temper the block loaded by issue(); append to the ring.  Needs gen - pos <= 48.
+    __device__ __forceinline__ void complete() {
+        const int i0 = gi + gl * WPL;
         const int so = gen & (RING - 1);
-        ring[so + gl] = w;
-        const unsigned long long bits = group_bits((w & maskN) <= mN);
-        okN = (okN & ~(((1ull << G) - 1) << so)) | (bits << so);
-        gen += G;
-        gi = gi + G == MT_N ? 0 : gi + G;
+        uint32_t v[WPL], bits = 0;
+#pragma unroll
+        for (int w = 0; w < WPL; w++) {
+            const uint32_t nxt = w + 1 < WPL ? pa[(w + 1) % WPL] : pn;
+            const uint32_t y = (pa[w] & 0x80000000u) | (nxt & 0x7fffffffu);
+            v[w] = px[w] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            const uint32_t t = mt_temper(v[w]);
+            ring[so + gl * WPL + w] = t;
+            bits |= ((t & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
+        }
+        if constexpr (WPL == 4) *(uint4*)(g_mt + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+        else if constexpr (WPL == 2) *(uint2*)(g_mt + i0) = make_uint2(v[0], v[1]);
+        else g_mt[i0] = v[0];
+        set_field(so, group_or<G>(bits));
+        gen += 16;
+        gi = gi + 16 == MT_N ? 0 : gi + 16;
+        pending = false;
     }
 
-    // continue the stream of a chain record: words [rpos, rge) of the current generation are
-    // already twisted but not consumed (fewer than 64 of them); temper them into the ring.
-    __device__ __forceinline__ void attach(uint32_t* lds_mt, uint32_t* lds_ring, int rpos, int rge, int gl_, int gshift_,
-                                           unsigned maskN_, unsigned mN_) {
-        mt = lds_mt, ring = lds_ring, gl = gl_, gshift = gshift_, maskN = maskN_, mN = mN_;
-        pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge, okN = 0;
-        for (int t0 = rpos & ~(G - 1); t0 < rge; t0 += G) {
-            const int t = t0 + gl;
-            const bool valid = t >= rpos && t < rge;
-            uint32_t w = 0;
-            if (valid) {
-                w = mt_temper(mt[t]);
-                ring[t & (RING - 1)] = w;
+    // continue the stream of a chain record: words [rpos, rge) of the current generation are already
+    // twisted but not consumed (fewer than 64 of them); temper them into the ring.
+    __device__ __forceinline__ void attach(uint32_t* mt_global, uint32_t* lds_ring, int rpos, int rge, int gl_, unsigned maskN_, unsigned mN_) {
+        g_mt = mt_global, ring = lds_ring, gl = gl_, maskN = maskN_, mN = mN_;
+        pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge;
+        ok_lo = ok_hi = 0, pending = false, pn = 0;
+#pragma unroll
+        for (int w = 0; w < WPL; w++) pa[w] = px[w] = 0;
+        for (int t0 = rpos & ~15; t0 < rge; t0 += 16) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int w = 0; w < WPL; w++) {
+                const int t = t0 + gl * WPL + w;
+                if (t >= rpos && t < rge) {
+                    const uint32_t x = mt_temper(g_mt[t]);
+                    ring[t & (RING - 1)] = x;
+                    bits |= ((x & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
+                }
             }
-            okN |= group_bits(valid && (w & maskN) <= mN) << (t0 & (RING - 1));
+            set_field(t0 & (RING - 1), group_or<G>(bits));
         }
     }
 };
@@ -384,31 +452,33 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
     return 1;
 }
 
-constexpr int SWEEP_WAVES = 1;  // wavefronts per workgroup; chains never interact, so no barrier exists
+// LDS per chain: ring[64] | stage[16] | board: pad[8], heights bytes, pad[8] | full_3d: queens packed (i | j<<8 | k<<16) [Q], occupancy bits
+constexpr int LDS_STAGE = RING;            // word offset of the energy_history staging block
+constexpr int LDS_STATE = RING + 16;       // word offset of the state
 
-// LDS per chain: mt[624] | ring[64] | board: pad, heights bytes, pad | full_3d: queens packed (i | j<<8 | k<<16) [Q], occupancy bits
-template <int MODE, int G>
-__global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a) {
+template <int MODE, int G, bool PATIENCE>
+__global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
-    constexpr int GEN_EVERY = G >= 16 ? 2 : 1;  // top the ring up every GEN_EVERY steps: the lanes of a wavefront refill together
+    constexpr int WPL = 16 / G;
     constexpr int LAST = MODE == MCQ_MODE_BOARD ? 5 : 6;  // sequential-draw stages of one proposal
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     const int gl = lane & (G - 1), grp = lane / G;
-    const long long chain = ((long long)blockIdx.x * SWEEP_WAVES + wave) * CPW + grp;
+    const long long chain = (long long)blockIdx.x * CPW + grp;
     const int N = a.N, Q = a.Q;
     bool active = chain < a.n_chains;
+    if (!PATIENCE && !active) return;  // no wave-wide operation below: idle groups of the last wavefront can leave
     const long long crow = active ? chain : 0;
 
-    uint32_t* mt = lds + (wave * CPW + grp) * a.chain_lds_words;
-    uint32_t* ring = mt + MT_N;
-    uint8_t* hts = (uint8_t*)(ring + RING + 8);  // board (the diagonal probes read up to N-1 bytes outside either end)
-    uint32_t* qn = ring + RING;                  // full_3d: packed queens
-    uint32_t* occ = qn + Q;                      // full_3d: N^3 occupancy bits
+    uint32_t* base = lds + grp * a.chain_lds_words;
+    uint32_t* ring = base;
+    uint32_t* stage = base + LDS_STAGE;
+    uint8_t* hts = (uint8_t*)(base + LDS_STATE + 8);  // board (the diagonal probes read up to N-1 bytes outside either end)
+    uint32_t* qn = base + LDS_STATE;                  // full_3d: packed queens
+    uint32_t* occ = qn + Q;                           // full_3d: N^3 occupancy bits
 
     // ---- load the chain record ----
-    const uint32_t* rec = a.ws + crow * (long long)a.rec_words;
-    for (int w = gl; w < MT_N; w += G) mt[w] = rec[w];
+    uint32_t* rec = a.ws + crow * (long long)a.rec_words;
     const uint8_t* rst = (const uint8_t*)(rec + REC_STATE);
     if (MODE == MCQ_MODE_BOARD) {
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
@@ -424,21 +494,20 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
     const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
     const unsigned maskN = a.maskN, maskQ = a.maskQ;
     Stream<G> rng;
-    rng.attach(mt, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, grp * G, maskN, mN);
+    rng.attach(rec, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN);
 
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
     int hist_len = (int)a.n_steps + 1;
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
-    int hv = E;         // lane gl stages history entry (block base + gl); entry 0 = E0
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
     const bool trace = a.out.energy_hist != nullptr;
-    int32_t* hist = trace ? a.out.energy_hist + crow * a.hist_stride + gl : nullptr;
+    int32_t* hist = trace ? a.out.energy_hist + crow * a.hist_stride + gl * WPL : nullptr;
     uint32_t* bits = a.out.accept_bits ? (uint32_t*)a.out.accept_bits + crow * a.bits_stride * 2 : nullptr;
     const int patience = a.patience < 0 ? 0x7fffffff : (a.patience > 0x7fffffff ? 0x7fffffff : (int)a.patience);
-    const bool has_patience = MODE == MCQ_MODE_BOARD && a.patience >= 0;
 
+    stage[0] = (uint32_t)E;  // history entry 0 = E0 (every lane of the group writes the same word)
     if (active) {
         if (gl == 0 && a.out.initial_energy) a.out.initial_energy[chain] = E;
         if (a.out.best_state) {
@@ -448,11 +517,10 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
     }
 
     const int n_steps = (int)a.n_steps;
-    for (int step = 0; step < n_steps; step++) {
-        // ---- wave-uniform per-step values (scalar loads / scalar ALU) ----
-        const double beta = a.beta_tab[step];
-        const bool bpos = beta > 0.0, bneg = beta < 0.0;
-        const float c32 = (float)(-beta * 1.4426950408889634);  // exp(-beta dE) = exp2(dE * c32)
+    for (int vstep = 0; vstep < n_steps; vstep++) {
+        // every live lane is at the same step; with early stopping the loop itself may become divergent
+        const int step = PATIENCE ? __builtin_amdgcn_readfirstlane(vstep) : vstep;
+        const float c32 = a.c32_tab[step];  // exp(-beta dE) = exp2(dE * c32); scalar load
 
         if (active) {
             // ---- proposal draws -----------------------------------------------------------------
@@ -463,81 +531,81 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
             int qi = 0;                  // full_3d
             uint32_t oldp = 0;
             uint32_t uw1 = 0, uw2 = 0;   // the two words of random()
-            int stage = 0;
-            bool topup = (step % GEN_EVERY) == 0;
+            int stage_no = 0;
+            // stream upkeep runs for every chain of the wavefront together: board steps use ~6.1 words, so one
+            // block of 16 per two steps keeps up; full_3d steps use ~8.1, so every step
+            bool service = MODE == MCQ_MODE_BOARD ? (step & 1) == 0 : true;
             for (;;) {
-                if (topup)
-                    while (rng.gen - rng.pos <= (uint32_t)(RING - G)) rng.round();
-                topup = true;  // a second pass means the ring ran dry
-                if (MODE == MCQ_MODE_BOARD && stage == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
+                if (service) {
+                    if (rng.pending) rng.complete();
+                    // the block lands at the next upkeep, after >= 10 (board: two steps) or >= 6 (full_3d) more
+                    // words were consumed, or earlier only if the ring ran dry: there is room for its 16 words
+                    if (rng.gen - rng.pos <= (MODE == MCQ_MODE_BOARD ? 58u : 54u)) rng.issue();
+                }
+                service = true;  // a second pass means the ring ran dry: finish the block in flight now
+                if (MODE == MCQ_MODE_BOARD && stage_no == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
                     // positions of the next four accepted words inside the 32 ring slots that follow pos
-                    const int s = rng.pos & (RING - 1);
-                    const uint32_t lo = (uint32_t)rng.okN, hi = (uint32_t)(rng.okN >> 32);
-                    uint32_t v = __builtin_amdgcn_alignbit((s & 32) ? lo : hi, (s & 32) ? hi : lo, (uint32_t)s & 31u);
-                    const uint32_t p1 = (uint32_t)__ffs(v) - 1u;
-                    v &= v - 1;
-                    const uint32_t p2 = (uint32_t)__ffs(v) - 1u;
-                    v &= v - 1;
-                    const uint32_t p3 = (uint32_t)__ffs(v) - 1u;
-                    v &= v - 1;
-                    const uint32_t p4 = (uint32_t)__ffs(v) - 1u;
-                    if (p4 <= 29u) {  // four accepted words, and the two words of the uniform still inside the view
+                    const uint32_t s = rng.pos & (RING - 1);
+                    const uint32_t v1 = __builtin_amdgcn_alignbit((s & 32u) ? rng.ok_lo : rng.ok_hi, (s & 32u) ? rng.ok_hi : rng.ok_lo, s & 31u);
+                    const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1);
+                    if (v4 & 0x3fffffffu) {  // a fourth accepted word, and the two words of the uniform still inside the view
+                        const uint32_t p1 = __builtin_ctz(v1), p2 = __builtin_ctz(v2), p3 = __builtin_ctz(v3), p4 = __builtin_ctz(v4);
                         const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)];
                         const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)];
                         pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
                         const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN);
-                        cell = pa * N + pb;
+                        cell = __mul24(pa, N) + pb;
                         old_k = hts[cell];
                         const bool use3 = c3 != old_k;
                         pc = use3 ? c3 : c4;
-                        if (use3 || c4 != old_k) {
-                            const uint32_t kp = use3 ? p3 : p4;
-                            uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
+                        const uint32_t kp = use3 ? p3 : p4;
+                        uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
+                        if (pc != old_k) {
                             rng.pos += kp + 3;
                             break;
                         }
                     }
                 }
                 // sequential: one word at a time from what the ring holds (nothing was consumed above)
-                while (rng.pos != rng.gen && stage < LAST) {
+                while (rng.pos != rng.gen && stage_no < LAST) {
                     const uint32_t w = ring[rng.pos & (RING - 1)];
                     rng.pos++;
                     const int vN = (int)(w & maskN);
                     const bool okN = (unsigned)vN <= mN;
                     if (MODE == MCQ_MODE_BOARD) {
-                        if (stage == 0) {
-                            if (okN) pa = vN, stage = 1;
-                        } else if (stage == 1) {
-                            if (okN) pb = vN, cell = pa * N + pb, old_k = hts[cell], stage = 2;
-                        } else if (stage == 2) {
-                            if (okN && vN != old_k) pc = vN, stage = 3;
-                        } else if (stage == 3) {
-                            uw1 = w, stage = 4;
+                        if (stage_no == 0) {
+                            if (okN) pa = vN, stage_no = 1;
+                        } else if (stage_no == 1) {
+                            if (okN) pb = vN, cell = pa * N + pb, old_k = hts[cell], stage_no = 2;
+                        } else if (stage_no == 2) {
+                            if (okN && vN != old_k) pc = vN, stage_no = 3;
+                        } else if (stage_no == 3) {
+                            uw1 = w, stage_no = 4;
                         } else {
-                            uw2 = w, stage = 5;
+                            uw2 = w, stage_no = 5;
                         }
                     } else {
-                        if (stage == 0) {
+                        if (stage_no == 0) {
                             const unsigned vQ = w & maskQ;
-                            if (vQ <= mQ) qi = (int)vQ, oldp = qn[qi], stage = 1;
-                        } else if (stage == 1) {
-                            if (okN) pa = vN, stage = 2;
-                        } else if (stage == 2) {
-                            if (okN) pb = vN, stage = 3;
-                        } else if (stage == 3) {
+                            if (vQ <= mQ) qi = (int)vQ, oldp = qn[qi], stage_no = 1;
+                        } else if (stage_no == 1) {
+                            if (okN) pa = vN, stage_no = 2;
+                        } else if (stage_no == 2) {
+                            if (okN) pb = vN, stage_no = 3;
+                        } else if (stage_no == 3) {
                             if (okN) {
                                 pc = vN;
                                 const int f = (pa * N + pb) * N + pc;
-                                stage = ((occ[f >> 5] >> (f & 31)) & 1u) ? 1 : 4;  // occupied: draw the triple again
+                                stage_no = ((occ[f >> 5] >> (f & 31)) & 1u) ? 1 : 4;  // occupied: draw the triple again
                             }
-                        } else if (stage == 4) {
-                            uw1 = w, stage = 5;
+                        } else if (stage_no == 4) {
+                            uw1 = w, stage_no = 5;
                         } else {
-                            uw2 = w, stage = 6;
+                            uw2 = w, stage_no = 6;
                         }
                     }
                 }
-                if (stage == LAST) break;
+                if (stage_no == LAST) break;
             }
 
             // ---- dE -------------------------------------------------------------------------------
@@ -550,42 +618,44 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
                 // and always scores -1 (it holds old_k): +4 below.
                 const int i = pa, j = pb;
                 const uint32_t Bo = 1u << old_k, Bn = 1u << pc;
-                int part = 0;
-#pragma unroll 1
+                const uint8_t* hrow = hts + __mul24(i, N);
+                int hn = 0, ho = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int m = gl; m < N; m += G) {
                     {  // row i: column (i, m)
                         const uint32_t d = (uint32_t)abs(m - j);
-                        const uint32_t h = hts[i * N + m];
+                        const uint32_t h = hrow[m];
                         const uint32_t Mo = Bo | (Bo << d) | (Bo >> d), Mn = Bn | (Bn << d) | (Bn >> d);
-                        part += (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
+                        hn += (Mn >> h) & 1u, ho += (Mo >> h) & 1u;
                     }
                     const uint32_t d = (uint32_t)abs(m - i);
                     const uint32_t Mo = Bo | (Bo << d) | (Bo >> d), Mn = Bn | (Bn << d) | (Bn >> d);
+                    const uint8_t* hm = hts + __mul24(m, N);
                     {  // column j: (m, j)
-                        const uint32_t h = hts[m * N + j];
-                        part += (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
+                        const uint32_t h = hm[j];
+                        hn += (Mn >> h) & 1u, ho += (Mo >> h) & 1u;
                     }
-                    {  // diagonal: (m, m - i + j)
+                    {  // diagonal: (m, m - i + j); out-of-board reads stay inside the chain's LDS and are discarded
                         const int j2 = m - i + j;
-                        const uint32_t h = hts[m * N + j2] & 31u;  // out-of-board reads stay inside the chain's LDS and are discarded
-                        const int c = (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
-                        part += (unsigned)j2 < (unsigned)N ? c : 0;
+                        const uint32_t h = hm[j2] & 31u;
+                        const bool in = (unsigned)j2 < (unsigned)N;
+                        hn += in ? (Mn >> h) & 1u : 0u, ho += in ? (Mo >> h) & 1u : 0u;
                     }
                     {  // anti-diagonal: (m, i + j - m)
                         const int j2 = i + j - m;
-                        const uint32_t h = hts[m * N + j2] & 31u;
-                        const int c = (int)((Mn >> h) & 1u) - (int)((Mo >> h) & 1u);
-                        part += (unsigned)j2 < (unsigned)N ? c : 0;
+                        const uint32_t h = hm[j2] & 31u;
+                        const bool in = (unsigned)j2 < (unsigned)N;
+                        hn += in ? (Mn >> h) & 1u : 0u, ho += in ? (Mo >> h) & 1u : 0u;
                     }
                 }
-                dE = group_sum<G>(part) + 4;
+                dE = group_sum<G>(hn - ho) + 4;
             } else {
                 // every other queen against the old and the new cell (mcmc.py:185-226)
                 const int ni = pa, nj = pb, nk = pc;
                 newp = (uint32_t)ni | ((uint32_t)nj << 8) | ((uint32_t)nk << 16);
                 const int oi = oldp & 255, oj = (oldp >> 8) & 255, ok_ = (oldp >> 16) & 255;
                 int part = 0;
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int c = gl; c < Q; c += G) {
                     const uint32_t pq = qn[c];
                     const int ci = pq & 255, cj = (pq >> 8) & 255, ck = (pq >> 16) & 255;
@@ -596,7 +666,9 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
             }
 
             // ---- accept iff u < min(1, exp(-beta dE)); the uniform is always drawn -------------------
-            const bool xneg = (bpos && dE > 0) || (bneg && dE < 0);  // x = -beta dE < 0; otherwise probability 1
+            // x = -beta dE < 0 iff beta and dE have the same sign (c32 has the sign of -beta); otherwise
+            // the probability is 1 (also for a NaN beta, like min(1.0, nan) in the reference).
+            const bool xneg = (c32 < 0.0f && dE > 0) || (c32 > 0.0f && dE < 0);
             bool acc = !xneg, exact = xneg;
             if (!exact_only) {
                 // u * 2^27 lies in [a27, a27 + 1); e27 = exp(x) * 2^27 within 3e-5 relative
@@ -608,7 +680,7 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
                 exact = xneg && !sure_acc && !sure_rej;
             }
             if (exact) {
-                const int r = accept_exact(beta, dE, uw1, uw2);
+                const int r = accept_exact(a.beta_tab[step], dE, uw1, uw2);
                 acc = (r & 1) != 0, ties += r >> 1;
             }
 
@@ -616,19 +688,21 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
             if (acc) {
                 accw |= 1u << (step & 31);
                 if (MODE == MCQ_MODE_BOARD) {
-                    if (gl == 0) hts[cell] = (uint8_t)pc;
-                } else if (gl == 0) {
+                    hts[cell] = (uint8_t)pc;  // every lane of the group writes the same byte
+                } else {
                     const int fo = ((int)(oldp & 255) * N + (int)((oldp >> 8) & 255)) * N + (int)((oldp >> 16) & 255);
                     const int fn = (pa * N + pb) * N + pc;
-                    occ[fo >> 5] &= ~(1u << (fo & 31));
-                    occ[fn >> 5] |= 1u << (fn & 31);
+                    if (gl == 0) {
+                        occ[fo >> 5] &= ~(1u << (fo & 31));
+                        occ[fn >> 5] |= 1u << (fn & 31);
+                    }
                     qn[qi] = newp;
                 }
                 E += dE;
                 n_acc++;
                 improved = E < best;
             }
-            no_imp = improved ? 0 : no_imp + 1;
+            if (PATIENCE) no_imp = improved ? 0 : no_imp + 1;
             if (improved) {
                 best = E;
                 if (a.out.best_state) {
@@ -644,29 +718,36 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES, 4) void mcq_sweep_kernel(KArgs a)
                 }
             }
 
-            if (has_patience && no_imp >= patience) {
+            const int e = step + 1;
+            if (PATIENCE && no_imp >= patience) {
                 // break BEFORE the append (experiments.py:349-353): entries 0..step are valid
                 active = false;
-                hist_len = step + 1;
-                if (trace && gl <= (step & (G - 1))) hist[step & ~(G - 1)] = hv;
+                hist_len = e;
+                if (trace)
+                    for (int w = 0; w < WPL; w++)
+                        if (gl * WPL + w <= (step & 15)) hist[(step & ~15) + w] = (int)stage[gl * WPL + w];
                 if (bits && gl == 0) bits[step >> 5] = accw;
             } else {
-                const int e = step + 1;
-                if ((e & (G - 1)) == gl) hv = E;
+                stage[e & 15] = (uint32_t)E;
                 if (improved) best_step = e;
+                if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
+                    if constexpr (WPL == 4) *(uint4*)(hist + e - 15) = *(const uint4*)(stage + gl * 4);
+                    else if constexpr (WPL == 2) *(uint2*)(hist + e - 15) = *(const uint2*)(stage + gl * 2);
+                    else hist[e - 15] = (int)stage[gl];
+                }
+                if ((step & 31) == 31) {
+                    if (bits && gl == 0) bits[step >> 5] = accw;
+                    accw = 0;
+                }
             }
         }
-        const int e = step + 1;
-        if ((e & (G - 1)) == G - 1 && trace && active) hist[e - (G - 1)] = hv;
-        if ((step & 31) == 31) {
-            if (bits && active && gl == 0) bits[step >> 5] = accw;
-            accw = 0;
-        }
-        if (has_patience && !__any(active)) break;
+        if (PATIENCE && !__any(active)) break;
     }
 
     if (active) {  // ran to n_steps: flush the partial last block and word
-        if (trace && (n_steps & (G - 1)) != G - 1 && gl <= (n_steps & (G - 1))) hist[n_steps & ~(G - 1)] = hv;
+        if (trace && (n_steps & 15) != 15)
+            for (int w = 0; w < WPL; w++)
+                if (gl * WPL + w <= (n_steps & 15)) hist[(n_steps & ~15) + w] = (int)stage[gl * WPL + w];
         if (bits && gl == 0 && (n_steps & 31) != 0) bits[n_steps >> 5] = accw;
     }
     if (chain < a.n_chains) {
@@ -734,14 +815,16 @@ int validate(const mcq_params* p) {
     if (p->trace != MCQ_TRACE_NONE && p->trace != MCQ_TRACE_I32) return fail(MCQ_EINVAL, "unknown trace mode");
     if (p->n_steps < 0 || p->n_steps > 2147483000LL) return fail(MCQ_EINVAL, "n_steps out of range [0, 2^31)");
     if (p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_chains");
-    if (p->lanes_per_chain != 0 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
-        return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 8 or 16");
+    if (p->lanes_per_chain != 0 && p->lanes_per_chain != 4 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
+        return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 4, 8 or 16");
     return MCQ_OK;
 }
 
-int rec_words_for(const mcq_params* p) { return REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4); }
+// 16-byte multiple: the sweep reads and writes the MT words of a record with dwordx4 accesses
+int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 3) & ~3; }
 
 size_t beta_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 8 + 255) & ~(size_t)255; }
+size_t c32_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 4 + 255) & ~(size_t)255; }
 
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
     memset(a, 0, sizeof *a);
@@ -760,28 +843,38 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->rec_words = rec_words_for(p);
     // board: the diagonal probes read up to N-1 bytes before / after the heights; 8 spare words on each
     // side keep those (discarded) reads inside the chain's own LDS slice.
-    a->chain_lds_words = MT_N + RING + (p->mode == MCQ_MODE_BOARD ? 8 + (a->Q + 3) / 4 + 8 : a->Q + (p->N * p->N * p->N + 31) / 32);
+    a->chain_lds_words = LDS_STATE + (p->mode == MCQ_MODE_BOARD ? 8 + (a->Q + 3) / 4 + 8 : a->Q + (p->N * p->N * p->N + 31) / 32);
+    a->chain_lds_words = (a->chain_lds_words + 3) & ~3;  // 16-byte multiple: the staging block is read with ds_read_b128
     a->beta_const = p->beta_const, a->beta_start = p->beta_start, a->beta_end = p->beta_end;
     a->n_steps = p->n_steps, a->n_chains = p->n_chains;
     a->patience = p->mode == MCQ_MODE_BOARD ? p->patience : -1;  // full_3d ignores early_stop_patience (experiments.py:199-279)
     a->hist_stride = p->hist_stride, a->bits_stride = p->bits_stride;
     a->beta_tab = (double*)ws;
-    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p));
+    a->c32_tab = (float*)((char*)ws + beta_tab_bytes(p));
+    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p));
     a->seeds = seeds, a->out = *out;
     if (p->trace == MCQ_TRACE_NONE) a->out.energy_hist = nullptr, a->out.accept_bits = nullptr;
     return MCQ_OK;
 }
 
-template <int MODE, int G>
+template <int MODE, int G, bool PATIENCE>
 int launch_sweep(const KArgs& a, hipStream_t s) {
-    constexpr int CPB = SWEEP_WAVES * (64 / G);
+    constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G>), dim3(grid), dim3(64 * SWEEP_WAVES), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
+}
+
+template <int MODE>
+int launch_sweep_mode(const KArgs& a, int G, hipStream_t s) {
+    const bool pat = MODE == MCQ_MODE_BOARD && a.patience >= 0;
+    if (G == 4) return pat ? launch_sweep<MODE, 4, true>(a, s) : launch_sweep<MODE, 4, false>(a, s);
+    if (G == 8) return pat ? launch_sweep<MODE, 8, true>(a, s) : launch_sweep<MODE, 8, false>(a, s);
+    return pat ? launch_sweep<MODE, 16, true>(a, s) : launch_sweep<MODE, 16, false>(a, s);
 }
 
 int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -817,9 +910,8 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
 
-    const int G = p->lanes_per_chain ? p->lanes_per_chain : 16;
-    if (p->mode == MCQ_MODE_BOARD) rc = G == 8 ? launch_sweep<MCQ_MODE_BOARD, 8>(a, s) : launch_sweep<MCQ_MODE_BOARD, 16>(a, s);
-    else rc = G == 8 ? launch_sweep<MCQ_MODE_FULL3D, 8>(a, s) : launch_sweep<MCQ_MODE_FULL3D, 16>(a, s);
+    const int G = p->lanes_per_chain ? p->lanes_per_chain : 4;
+    rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     return MCQ_OK;
@@ -846,7 +938,7 @@ size_t mcq_state_bytes(int32_t N, int32_t mode) {
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
-    return beta_tab_bytes(p) + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,

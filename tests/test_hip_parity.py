@@ -13,7 +13,7 @@ from tests import util
 
 abi = mcq_amd.abi
 pytestmark = pytest.mark.gpu
-LANES = (8, 16)
+LANES = (4, 8, 16)
 
 
 def _group_key(c):
