@@ -190,6 +190,13 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// |a - b| of two small non-negative integers in one instruction
+__device__ __forceinline__ uint32_t abs_diff(int a, int b) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // two distinct cells attack each other iff they share one of the 13 lines: every non-zero
 // coordinate offset has the same magnitude.
 __device__ __forceinline__ bool on_a_line(int di, int dj, int dk) {
@@ -350,7 +357,8 @@ __device__ __forceinline__ uint32_t group_or(uint32_t u) {
 template <int G>
 struct Stream {
     static constexpr int WPL = 16 / G;  // words per lane in a block
-    uint32_t* g_mt;
+    char* wbase;    // wave-uniform: record of the wavefront's first chain (kept in scalar registers)
+    uint32_t coff;  // byte offset of this chain's record from wbase
     uint32_t* ring;
     uint32_t pos, gen;
     int gi;
@@ -359,6 +367,15 @@ struct Stream {
     uint32_t pa[WPL], pn, px[WPL];
     int gl;
     unsigned maskN, mN;
+    uint32_t tc1, tc2;  // tempering masks, kept in scalar registers so that (y << s) & c ^ y is one 3-input op
+
+    __device__ __forceinline__ uint32_t temper(uint32_t y) const {
+        y ^= y >> 11;
+        y ^= (y << 7) & tc1;
+        y ^= (y << 15) & tc2;
+        y ^= y >> 18;
+        return y;
+    }
 
     __device__ __forceinline__ void set_field(int so, uint32_t bits16) {
         const uint32_t sh = (uint32_t)so & 16u;
@@ -368,24 +385,27 @@ struct Stream {
         ok_hi = (so & 32) ? upd : ok_hi;
     }
 
+    // MT word `idx` of this chain: uniform base + 32-bit offset, so the address needs no 64-bit vector math
+    __device__ __forceinline__ uint32_t* word(int idx) const { return (uint32_t*)(wbase + (coff + 4u * (uint32_t)idx)); }
+
     // load the inputs of block gi: words i, i+1 and (i+397) mod 624 for the lane's WPL words
     __device__ __forceinline__ void issue() {
         const int i0 = gi + gl * WPL;
         if constexpr (WPL == 4) {
-            const uint4 q = *(const uint4*)(g_mt + i0);
+            const uint4 q = *(const uint4*)word(i0);
             pa[0] = q.x, pa[1] = q.y, pa[2] = q.z, pa[3] = q.w;
         } else if constexpr (WPL == 2) {
-            const uint2 q = *(const uint2*)(g_mt + i0);
+            const uint2 q = *(const uint2*)word(i0);
             pa[0] = q.x, pa[1] = q.y;
         } else {
-            pa[0] = g_mt[i0];
+            pa[0] = *word(i0);
         }
         const int in = i0 + WPL;
-        pn = g_mt[in == MT_N ? 0 : in];  // word 623 pairs with the NEW word 0, already written back
+        pn = *word(in == MT_N ? 0 : in);  // word 623 pairs with the NEW word 0, already written back
 #pragma unroll
         for (int w = 0; w < WPL; w++) {
             const int ix = i0 + w + MT_M;
-            px[w] = g_mt[ix >= MT_N ? ix - MT_N : ix];
+            px[w] = *word(ix >= MT_N ? ix - MT_N : ix);
         }
         pending = true;
     }
@@ -400,13 +420,13 @@ struct Stream {
             const uint32_t nxt = w + 1 < WPL ? pa[(w + 1) % WPL] : pn;
             const uint32_t y = (pa[w] & 0x80000000u) | (nxt & 0x7fffffffu);
             v[w] = px[w] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            const uint32_t t = mt_temper(v[w]);
+            const uint32_t t = temper(v[w]);
             ring[so + gl * WPL + w] = t;
             bits |= ((t & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
         }
-        if constexpr (WPL == 4) *(uint4*)(g_mt + i0) = make_uint4(v[0], v[1], v[2], v[3]);
-        else if constexpr (WPL == 2) *(uint2*)(g_mt + i0) = make_uint2(v[0], v[1]);
-        else g_mt[i0] = v[0];
+        if constexpr (WPL == 4) *(uint4*)word(i0) = make_uint4(v[0], v[1], v[2], v[3]);
+        else if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
+        else *word(i0) = v[0];
         set_field(so, group_or<G>(bits));
         gen += 16;
         gi = gi + 16 == MT_N ? 0 : gi + 16;
@@ -415,8 +435,9 @@ struct Stream {
 
     // continue the stream of a chain record: words [rpos, rge) of the current generation are already
     // twisted but not consumed (fewer than 64 of them); temper them into the ring.
-    __device__ __forceinline__ void attach(uint32_t* mt_global, uint32_t* lds_ring, int rpos, int rge, int gl_, unsigned maskN_, unsigned mN_) {
-        g_mt = mt_global, ring = lds_ring, gl = gl_, maskN = maskN_, mN = mN_;
+    __device__ __forceinline__ void attach(char* wave_base, uint32_t chain_off, uint32_t* lds_ring, int rpos, int rge, int gl_, unsigned maskN_,
+                                           unsigned mN_, uint32_t c1, uint32_t c2) {
+        wbase = wave_base, coff = chain_off, ring = lds_ring, gl = gl_, maskN = maskN_, mN = mN_, tc1 = c1, tc2 = c2;
         pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge;
         ok_lo = ok_hi = 0, pending = false, pn = 0;
 #pragma unroll
@@ -427,7 +448,7 @@ struct Stream {
             for (int w = 0; w < WPL; w++) {
                 const int t = t0 + gl * WPL + w;
                 if (t >= rpos && t < rge) {
-                    const uint32_t x = mt_temper(g_mt[t]);
+                    const uint32_t x = temper(*word(t));
                     ring[t & (RING - 1)] = x;
                     bits |= ((x & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
                 }
@@ -456,7 +477,9 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
 constexpr int LDS_STAGE = RING;            // word offset of the energy_history staging block
 constexpr int LDS_STATE = RING + 16;       // word offset of the state
 
-template <int MODE, int G, bool PATIENCE>
+// NT > 0: ceil(N / G) is a compile-time constant, so the dE probes of a step are issued as one straight-line block
+// (all their LDS reads in flight together); NT == 0: run-time loop over the probe passes.
+template <int MODE, int G, bool PATIENCE, int NT>
 __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
@@ -493,8 +516,12 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     }
     const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
     const unsigned maskN = a.maskN, maskQ = a.maskQ;
+    uint32_t tc1 = 0x9d2c5680u, tc2 = 0xefc60000u;
+    asm volatile("" : "+s"(tc1), "+s"(tc2));  // opaque scalars: no literal operands in the tempering
+    const uint32_t rec_bytes = (uint32_t)a.rec_words * 4u;
+    char* wave_base = (char*)(a.ws + (long long)blockIdx.x * CPW * (long long)a.rec_words);
     Stream<G> rng;
-    rng.attach(rec, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN);
+    rng.attach(wave_base, active ? (uint32_t)grp * rec_bytes : 0u, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN, tc1, tc2);
 
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
@@ -516,11 +543,18 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         }
     }
 
+    // the tables were written by an earlier kernel and are read-only here: the constant address space
+    // lets the compiler fetch them with scalar loads (one s_load per step instead of a vector load)
+    typedef const __attribute__((address_space(4))) float* const_f32_ptr;
+    typedef const __attribute__((address_space(4))) double* const_f64_ptr;
+    const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)a.c32_tab;
+    const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)a.beta_tab;
+
     const int n_steps = (int)a.n_steps;
     for (int vstep = 0; vstep < n_steps; vstep++) {
         // every live lane is at the same step; with early stopping the loop itself may become divergent
         const int step = PATIENCE ? __builtin_amdgcn_readfirstlane(vstep) : vstep;
-        const float c32 = a.c32_tab[step];  // exp(-beta dE) = exp2(dE * c32); scalar load
+        const float c32 = c32_tab[step];  // exp(-beta dE) = exp2(dE * c32)
 
         if (active) {
             // ---- proposal draws -----------------------------------------------------------------
@@ -618,37 +652,37 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 // and always scores -1 (it holds old_k): +4 below.
                 const int i = pa, j = pb;
                 const uint32_t Bo = 1u << old_k, Bn = 1u << pc;
+                // LDS byte addresses: row i starts at hrow; (m, j) = hj + m*N; (m, m-i+j) = hd + m*(N+1); (m, i+j-m) = ha + m*(N-1)
                 const uint8_t* hrow = hts + __mul24(i, N);
-                int hn = 0, ho = 0;
+                const uint8_t* hj = hts + j;
+                const uint8_t* hd = hj - i;
+                const uint8_t* ha = hj + i;
+                const int dji = j - i, sij = i + j;
+                int acc = 0;
+                auto probe = [&](int m, bool in_board) {
+                    const int mN_ = __mul24(m, N);
+                    const uint32_t hr = hrow[m], hc = hj[mN_], hdg = hd[mN_ + m], han = ha[mN_ - m];
+                    const uint32_t dr = abs_diff(m, j), dc = abs_diff(m, i);
+                    const uint32_t Mor = Bo | (Bo << dr) | (Bo >> dr), Mnr = Bn | (Bn << dr) | (Bn >> dr);
+                    const uint32_t Moc = Bo | (Bo << dc) | (Bo >> dc), Mnc = Bn | (Bn << dc) | (Bn >> dc);
+                    // +1 for a hit on the new height, -1 (sign-extended bit) for a hit on the old one
+                    const int cr = (int)__builtin_amdgcn_ubfe(Mnr, hr, 1) + __builtin_amdgcn_sbfe((int)Mor, hr, 1);
+                    const int cc = (int)__builtin_amdgcn_ubfe(Mnc, hc, 1) + __builtin_amdgcn_sbfe((int)Moc, hc, 1);
+                    // diagonals: out-of-board probes read some other byte of the chain's LDS slice and are discarded
+                    const int cd = (int)__builtin_amdgcn_ubfe(Mnc, hdg, 1) + __builtin_amdgcn_sbfe((int)Moc, hdg, 1);
+                    const int ca = (int)__builtin_amdgcn_ubfe(Mnc, han, 1) + __builtin_amdgcn_sbfe((int)Moc, han, 1);
+                    acc += in_board ? cr + cc : 0;
+                    acc += in_board && (unsigned)(m + dji) < (unsigned)N ? cd : 0;
+                    acc += in_board && (unsigned)(sij - m) < (unsigned)N ? ca : 0;
+                };
+                if constexpr (NT > 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) probe(gl + t * G, t + 1 < NT || gl + t * G < N);
+                } else {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int m = gl; m < N; m += G) {
-                    {  // row i: column (i, m)
-                        const uint32_t d = (uint32_t)abs(m - j);
-                        const uint32_t h = hrow[m];
-                        const uint32_t Mo = Bo | (Bo << d) | (Bo >> d), Mn = Bn | (Bn << d) | (Bn >> d);
-                        hn += (Mn >> h) & 1u, ho += (Mo >> h) & 1u;
-                    }
-                    const uint32_t d = (uint32_t)abs(m - i);
-                    const uint32_t Mo = Bo | (Bo << d) | (Bo >> d), Mn = Bn | (Bn << d) | (Bn >> d);
-                    const uint8_t* hm = hts + __mul24(m, N);
-                    {  // column j: (m, j)
-                        const uint32_t h = hm[j];
-                        hn += (Mn >> h) & 1u, ho += (Mo >> h) & 1u;
-                    }
-                    {  // diagonal: (m, m - i + j); out-of-board reads stay inside the chain's LDS and are discarded
-                        const int j2 = m - i + j;
-                        const uint32_t h = hm[j2] & 31u;
-                        const bool in = (unsigned)j2 < (unsigned)N;
-                        hn += in ? (Mn >> h) & 1u : 0u, ho += in ? (Mo >> h) & 1u : 0u;
-                    }
-                    {  // anti-diagonal: (m, i + j - m)
-                        const int j2 = i + j - m;
-                        const uint32_t h = hm[j2] & 31u;
-                        const bool in = (unsigned)j2 < (unsigned)N;
-                        hn += in ? (Mn >> h) & 1u : 0u, ho += in ? (Mo >> h) & 1u : 0u;
-                    }
+                    for (int m = gl; m < N; m += G) probe(m, true);
                 }
-                dE = group_sum<G>(hn - ho) + 4;
+                dE = group_sum<G>(acc) + 4;
             } else {
                 // every other queen against the old and the new cell (mcmc.py:185-226)
                 const int ni = pa, nj = pb, nk = pc;
@@ -680,7 +714,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 exact = xneg && !sure_acc && !sure_rej;
             }
             if (exact) {
-                const int r = accept_exact(a.beta_tab[step], dE, uw1, uw2);
+                const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
                 acc = (r & 1) != 0, ties += r >> 1;
             }
 
@@ -857,24 +891,35 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     return MCQ_OK;
 }
 
-template <int MODE, int G, bool PATIENCE>
+template <int MODE, int G, bool PATIENCE, int NT>
 int launch_sweep(const KArgs& a, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
 
+template <int MODE, int G>
+int launch_sweep_g(const KArgs& a, hipStream_t s) {
+    const bool pat = MODE == MCQ_MODE_BOARD && a.patience >= 0;
+    if (MODE == MCQ_MODE_BOARD && G == 4 && !pat) {  // straight-line probe blocks for the common board sizes
+        const int nt = (a.N + G - 1) / G;
+        if (nt == 3) return launch_sweep<MODE, G, false, 3>(a, s);  // N = 9..12
+        if (nt == 4) return launch_sweep<MODE, G, false, 4>(a, s);  // N = 13..16
+        if (nt == 6) return launch_sweep<MODE, G, false, 6>(a, s);  // N = 21..24
+    }
+    return pat ? launch_sweep<MODE, G, true, 0>(a, s) : launch_sweep<MODE, G, false, 0>(a, s);
+}
+
 template <int MODE>
 int launch_sweep_mode(const KArgs& a, int G, hipStream_t s) {
-    const bool pat = MODE == MCQ_MODE_BOARD && a.patience >= 0;
-    if (G == 4) return pat ? launch_sweep<MODE, 4, true>(a, s) : launch_sweep<MODE, 4, false>(a, s);
-    if (G == 8) return pat ? launch_sweep<MODE, 8, true>(a, s) : launch_sweep<MODE, 8, false>(a, s);
-    return pat ? launch_sweep<MODE, 16, true>(a, s) : launch_sweep<MODE, 16, false>(a, s);
+    if (G == 4) return launch_sweep_g<MODE, 4>(a, s);
+    if (G == 8) return launch_sweep_g<MODE, 8>(a, s);
+    return launch_sweep_g<MODE, 16>(a, s);
 }
 
 int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,

@@ -46,6 +46,13 @@ CASES = [
     (3, "board", "latin", {"type": "constant", "beta_const": 0.0}, 700, 17, None),
     (32, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 2.0}, 300, 5, None),
     (2, "full_3d", "random", {"type": "constant", "beta_const": 2.0}, 500, 6, None),
+    # board sizes on either edge of the unrolled-probe specialisations (ceil(N/4) = 3, 4, 6) and around them
+    (9, "board", "random", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}, 1500, 19, None),
+    (10, "board", "latin", {"type": "constant", "beta_const": 1.0}, 1000, 12, None),
+    (13, "board", "klarner", {"type": "constant", "beta_const": 0.3}, 1000, 11, None),
+    (16, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 800, 20, None),
+    (21, "board", "random", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 600, 9, None),
+    (25, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 400, 7, None),
 ]
 
 
