@@ -854,8 +854,8 @@ int validate(const mcq_params* p) {
     return MCQ_OK;
 }
 
-// 16-byte multiple: the sweep reads and writes the MT words of a record with dwordx4 accesses
-int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 3) & ~3; }
+// 64-byte multiple: the sweep reads and writes the MT words of a record in aligned 64-byte blocks
+int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 15) & ~15; }
 
 size_t beta_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 8 + 255) & ~(size_t)255; }
 size_t c32_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 4 + 255) & ~(size_t)255; }
