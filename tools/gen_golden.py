@@ -216,6 +216,64 @@ def gen_plumbing(ref_path):
     }
 
 
+def gen_drivers(ref_path):
+    """Small runs of the reference's experiment drivers (plot=False): seed derivations, labels, result dicts."""
+    import contextlib
+    import io
+
+    ex = _ref(ref_path)
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = ex.run_beta_start_end_pairs(N=6, n_steps=400, beta_start_ends=[[0.5, 3.0], [1.0, 5.0], [0.1, 2.0]],
+                                        annealing_type="linear_annealing", init_mode="random", n_runs=3, base_seed=42,
+                                        verbose=False, plot=False, mcmc_type="board", early_stop_patience=None)
+        out["pairs"] = {"args": {"N": 6, "n_steps": 400, "beta_start_ends": [[0.5, 3.0], [1.0, 5.0], [0.1, 2.0]],
+                                 "annealing_type": "linear_annealing", "init_mode": "random", "n_runs": 3, "base_seed": 42,
+                                 "mcmc_type": "board", "early_stop_patience": None},
+                        "best": {k: [int(b) for b in v] for k, v in r["all_best_energies"].items()},
+                        "final": {k: [int(h[-1]) for h in v] for k, v in r["all_histories"].items()},
+                        "hist_sum": {k: [int(np.sum(h)) for h in v] for k, v in r["all_histories"].items()}}
+        sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+        m = ex.measure_min_energy_vs_N(Ns=[3, 4, 6], n_steps=300, beta_schedule=_schedule(ex, sp, 300), schedule_params=sp,
+                                       init_modes=["random", "latin", "klarner"], n_runs=3, base_seed=42, verbose=False,
+                                       plot=False, mcmc_type="board", early_stop_patience=100)
+        out["min_vs_N"] = {"args": {"Ns": [3, 4, 6], "n_steps": 300, "schedule_params": sp, "init_modes": ["random", "latin", "klarner"],
+                                    "n_runs": 3, "base_seed": 42, "mcmc_type": "board", "early_stop_patience": 100},
+                           "results": {im: {"all_min": [[int(x) for x in a] for a in v["all_min_energies"]],
+                                            "all_stb": [[int(x) for x in a] for a in v["all_steps_to_best"]],
+                                            "mean_min": [float(x) for x in v["mean_min_energies"]],
+                                            "std_min": [float(x) for x in v["std_min_energies"]],
+                                            "mean_stb": [float(x) for x in v["mean_steps_to_best"]],
+                                            "std_stb": [float(x) for x in v["std_steps_to_best"]]}
+                                       for im, v in m["results"].items()}}
+        c = ex.run_compare_beta_end(Ns=[4, 5], n_steps=300, beta_start_ends=[[1.0, 3.0], [1.0, 5.0]],
+                                    annealing_type="exponential_annealing", init_mode="latin", n_runs=2, base_seed=7,
+                                    verbose=False, plot=False, mcmc_type="full_3d", early_stop_patience=None)
+        out["compare"] = {"args": {"Ns": [4, 5], "n_steps": 300, "beta_start_ends": [[1.0, 3.0], [1.0, 5.0]],
+                                   "annealing_type": "exponential_annealing", "init_mode": "latin", "n_runs": 2, "base_seed": 7,
+                                   "mcmc_type": "full_3d", "early_stop_patience": None},
+                          "N1": c["N1"], "N2": c["N2"],
+                          "best_N1": {k: [int(b) for b in v] for k, v in c["result_N1"]["all_best_energies"].items()},
+                          "best_N2": {k: [int(b) for b in v] for k, v in c["result_N2"]["all_best_energies"].items()}}
+        # acceptance binning of the reference's plot helper, re-derived from its inputs
+        sp2 = {"type": "constant", "beta_const": 1.0}
+        h, b, _t, acc, rej, _s = ex.run_experiment(N=5, n_steps=1000, init_mode="random", beta_schedule=_schedule(ex, sp2, 1000),
+                                                  n_runs=2, base_seed=3, verbose=False, n_workers=2, schedule_params=sp2,
+                                                  mcmc_type="board", early_stop_patience=None)
+        edges = np.linspace(0, 1000, 101)
+        edges[-1] = 1000
+        a_all, r_all = np.concatenate(acc), np.concatenate(rej)
+        rates = []
+        for i in range(100):
+            if i == 99:
+                a = np.sum((a_all >= edges[i]) & (a_all <= edges[i + 1])); rr = np.sum((r_all >= edges[i]) & (r_all <= edges[i + 1]))
+            else:
+                a = np.sum((a_all >= edges[i]) & (a_all < edges[i + 1])); rr = np.sum((r_all >= edges[i]) & (r_all < edges[i + 1]))
+            rates.append(float(a / (a + rr)) if a + rr else None)
+        out["acceptance"] = {"args": {"N": 5, "n_steps": 1000, "schedule_params": sp2, "n_runs": 2, "base_seed": 3}, "rates": rates}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -229,6 +287,7 @@ def main():
     manifest["analytic"] = gen_analytic(args.reference)
     manifest["beta"] = gen_beta(args.reference, OUT)
     manifest["plumbing"] = gen_plumbing(args.reference)
+    manifest["drivers"] = gen_drivers(args.reference)
 
     cases = chain_cases()
     with ProcessPoolExecutor(max_workers=args.workers) as pool:
