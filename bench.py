@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--N", type=int, default=12)
     ap.add_argument("--mcmc-type", default="board", choices=["board", "full_3d"])
     ap.add_argument("--schedule", default="linear_annealing")
-    ap.add_argument("--lanes", type=int, default=4, help="lanes of a wavefront per chain (4, 8 or 16)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (4, 8 or 16; 0 = library default)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=1024)
@@ -153,7 +153,7 @@ def main():
                         f"{sp.get('beta_start', sp.get('beta_const'))}->{sp.get('beta_end', '')} "
                         f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace else 'none'}",
             "chains_total": total_chains,
-            "lanes_per_chain": int(run.p.lanes_per_chain),
+            "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes(run.p.mode)),
             "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summary all-reduce (MIN/SUM)",
         },
         "min_energy": min_energy,

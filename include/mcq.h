@@ -118,6 +118,9 @@ int mcq_abi_version(void);
 const char* mcq_last_error(void);
 int mcq_device_count(void);
 
+/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0 (board: 4, full_3d: 8) */
+int32_t mcq_default_lanes(int32_t mode);
+
 /* bytes of one chain's state record in best_state / final_state; 0 on bad arguments */
 size_t mcq_state_bytes(int32_t N, int32_t mode);
 

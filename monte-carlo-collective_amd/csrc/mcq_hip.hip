@@ -46,6 +46,8 @@
 
 #include "../../include/mcq.h"
 
+extern "C" int32_t mcq_default_lanes(int32_t mode);
+
 namespace {
 
 constexpr int MT_N = 624;
@@ -354,7 +356,7 @@ __device__ __forceinline__ uint32_t group_or(uint32_t u) {
 // rejection test of randint(0, N)).
 //   pos, gen   absolute counters of consumed / generated words; ring slot = counter & 63
 //   gi         MT index of the next block to generate (multiple of 16, wraps at 624)
-template <int G>
+template <int G, bool HASQ>
 struct Stream {
     static constexpr int WPL = 16 / G;  // words per lane in a block
     char* wbase;    // wave-uniform: record of the wavefront's first chain (kept in scalar registers)
@@ -362,11 +364,12 @@ struct Stream {
     uint32_t* ring;
     uint32_t pos, gen;
     int gi;
-    uint32_t ok_lo, ok_hi;
+    uint32_t ok_lo, ok_hi;    // bit s: the word in ring slot s passes (w & maskN) <= N-1  (randint(0, N))
+    uint32_t okq_lo, okq_hi;  // HASQ: the same for (w & maskQ) <= Q-1                      (randint(0, Q), full_3d)
     bool pending;
     uint32_t pa[WPL], pn, px[WPL];
     int gl;
-    unsigned maskN, mN;
+    unsigned maskN, mN, maskQ, mQ;
     uint32_t tc1, tc2;  // tempering masks, kept in scalar registers so that (y << s) & c ^ y is one 3-input op
 
     __device__ __forceinline__ uint32_t temper(uint32_t y) const {
@@ -377,12 +380,16 @@ struct Stream {
         return y;
     }
 
-    __device__ __forceinline__ void set_field(int so, uint32_t bits16) {
+    static __device__ __forceinline__ void set_field(uint32_t& lo, uint32_t& hi, int so, uint32_t bits16) {
         const uint32_t sh = (uint32_t)so & 16u;
-        const uint32_t half = (so & 32) ? ok_hi : ok_lo;
+        const uint32_t half = (so & 32) ? hi : lo;
         const uint32_t upd = (half & ~(0xFFFFu << sh)) | (bits16 << sh);
-        ok_lo = (so & 32) ? ok_lo : upd;
-        ok_hi = (so & 32) ? upd : ok_hi;
+        lo = (so & 32) ? lo : upd;
+        hi = (so & 32) ? upd : hi;
+    }
+    // accept bits of the 32 ring slots that follow pos
+    static __device__ __forceinline__ uint32_t view(uint32_t lo, uint32_t hi, uint32_t s) {
+        return __builtin_amdgcn_alignbit((s & 32u) ? lo : hi, (s & 32u) ? hi : lo, s & 31u);
     }
 
     // MT word `idx` of this chain: uniform base + 32-bit offset, so the address needs no 64-bit vector math
@@ -414,7 +421,7 @@ struct Stream {
     __device__ __forceinline__ void complete() {
         const int i0 = gi + gl * WPL;
         const int so = gen & (RING - 1);
-        uint32_t v[WPL], bits = 0;
+        uint32_t v[WPL], bits = 0, bitsq = 0;
 #pragma unroll
         for (int w = 0; w < WPL; w++) {
             const uint32_t nxt = w + 1 < WPL ? pa[(w + 1) % WPL] : pn;
@@ -423,11 +430,13 @@ struct Stream {
             const uint32_t t = temper(v[w]);
             ring[so + gl * WPL + w] = t;
             bits |= ((t & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
+            if (HASQ) bitsq |= ((t & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
         }
         if constexpr (WPL == 4) *(uint4*)word(i0) = make_uint4(v[0], v[1], v[2], v[3]);
         else if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
         else *word(i0) = v[0];
-        set_field(so, group_or<G>(bits));
+        set_field(ok_lo, ok_hi, so, group_or<G>(bits));
+        if (HASQ) set_field(okq_lo, okq_hi, so, group_or<G>(bitsq));
         gen += 16;
         gi = gi + 16 == MT_N ? 0 : gi + 16;
         pending = false;
@@ -436,14 +445,15 @@ struct Stream {
     // continue the stream of a chain record: words [rpos, rge) of the current generation are already
     // twisted but not consumed (fewer than 64 of them); temper them into the ring.
     __device__ __forceinline__ void attach(char* wave_base, uint32_t chain_off, uint32_t* lds_ring, int rpos, int rge, int gl_, unsigned maskN_,
-                                           unsigned mN_, uint32_t c1, uint32_t c2) {
-        wbase = wave_base, coff = chain_off, ring = lds_ring, gl = gl_, maskN = maskN_, mN = mN_, tc1 = c1, tc2 = c2;
+                                           unsigned mN_, unsigned maskQ_, unsigned mQ_, uint32_t c1, uint32_t c2) {
+        wbase = wave_base, coff = chain_off, ring = lds_ring, gl = gl_, maskN = maskN_, mN = mN_, maskQ = maskQ_, mQ = mQ_, tc1 = c1, tc2 = c2;
+        okq_lo = okq_hi = 0;
         pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge;
         ok_lo = ok_hi = 0, pending = false, pn = 0;
 #pragma unroll
         for (int w = 0; w < WPL; w++) pa[w] = px[w] = 0;
         for (int t0 = rpos & ~15; t0 < rge; t0 += 16) {
-            uint32_t bits = 0;
+            uint32_t bits = 0, bitsq = 0;
 #pragma unroll
             for (int w = 0; w < WPL; w++) {
                 const int t = t0 + gl * WPL + w;
@@ -451,9 +461,11 @@ struct Stream {
                     const uint32_t x = temper(*word(t));
                     ring[t & (RING - 1)] = x;
                     bits |= ((x & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
+                    bitsq |= ((x & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
                 }
             }
-            set_field(t0 & (RING - 1), group_or<G>(bits));
+            set_field(ok_lo, ok_hi, t0 & (RING - 1), group_or<G>(bits));
+            if (HASQ) set_field(okq_lo, okq_hi, t0 & (RING - 1), group_or<G>(bitsq));
         }
     }
 };
@@ -473,9 +485,10 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
     return 1;
 }
 
-// LDS per chain: ring[64] | stage[16] | board: pad[8], heights bytes, pad[8] | full_3d: queens packed (i | j<<8 | k<<16) [Q], occupancy bits
+// LDS per chain: ring[64] | stage[16] | board: pad[8], heights bytes, pad[8] | full_3d: pad[32], column words [Q], pad[32], queens uint16 [Q]
 constexpr int LDS_STAGE = RING;            // word offset of the energy_history staging block
 constexpr int LDS_STATE = RING + 16;       // word offset of the state
+constexpr int FULL_PAD = 32;               // full_3d: spare words on either side of the column words (N <= 32)
 
 // NT > 0: ceil(N / G) is a compile-time constant, so the dE probes of a step are issued as one straight-line block
 // (all their LDS reads in flight together); NT == 0: run-time loop over the probe passes.
@@ -497,8 +510,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     uint32_t* ring = base;
     uint32_t* stage = base + LDS_STAGE;
     uint8_t* hts = (uint8_t*)(base + LDS_STATE + 8);  // board (the diagonal probes read up to N-1 bytes outside either end)
-    uint32_t* qn = base + LDS_STATE;                  // full_3d: packed queens
-    uint32_t* occ = qn + Q;                           // full_3d: N^3 occupancy bits
+    // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
+    // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
+    uint32_t* colw = base + LDS_STATE + FULL_PAD;
+    uint16_t* qn = (uint16_t*)(colw + Q + FULL_PAD);
 
     // ---- load the chain record ----
     uint32_t* rec = a.ws + crow * (long long)a.rec_words;
@@ -506,12 +521,11 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     if (MODE == MCQ_MODE_BOARD) {
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
     } else {
-        const int occ_words = (N * N * N + 31) >> 5;
-        for (int w = gl; w < occ_words; w += G) occ[w] = 0;
-        for (int c = gl; c < Q; c += G) qn[c] = (uint32_t)rst[3 * c] | ((uint32_t)rst[3 * c + 1] << 8) | ((uint32_t)rst[3 * c + 2] << 16);
+        for (int w = gl; w < Q; w += G) colw[w] = 0;
         for (int c = gl; c < Q; c += G) {
-            const int f = (rst[3 * c] * N + rst[3 * c + 1]) * N + rst[3 * c + 2];
-            atomicOr(&occ[f >> 5], 1u << (f & 31));
+            const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
+            qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
+            atomicOr(&colw[qi_ * N + qj_], 1u << qk_);
         }
     }
     const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
@@ -520,8 +534,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     asm volatile("" : "+s"(tc1), "+s"(tc2));  // opaque scalars: no literal operands in the tempering
     const uint32_t rec_bytes = (uint32_t)a.rec_words * 4u;
     char* wave_base = (char*)(a.ws + (long long)blockIdx.x * CPW * (long long)a.rec_words);
-    Stream<G> rng;
-    rng.attach(wave_base, active ? (uint32_t)grp * rec_bytes : 0u, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN, tc1, tc2);
+    Stream<G, MODE == MCQ_MODE_FULL3D> rng;
+    rng.attach(wave_base, active ? (uint32_t)grp * rec_bytes : 0u, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN, maskQ, mQ, tc1, tc2);
 
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
@@ -580,7 +594,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 if (MODE == MCQ_MODE_BOARD && stage_no == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
                     // positions of the next four accepted words inside the 32 ring slots that follow pos
                     const uint32_t s = rng.pos & (RING - 1);
-                    const uint32_t v1 = __builtin_amdgcn_alignbit((s & 32u) ? rng.ok_lo : rng.ok_hi, (s & 32u) ? rng.ok_hi : rng.ok_lo, s & 31u);
+                    const uint32_t v1 = rng.view(rng.ok_lo, rng.ok_hi, s);
                     const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1);
                     if (v4 & 0x3fffffffu) {  // a fourth accepted word, and the two words of the uniform still inside the view
                         const uint32_t p1 = __builtin_ctz(v1), p2 = __builtin_ctz(v2), p3 = __builtin_ctz(v3), p4 = __builtin_ctz(v4);
@@ -596,6 +610,37 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
                         if (pc != old_k) {
                             rng.pos += kp + 3;
+                            break;
+                        }
+                    }
+                }
+                if (MODE == MCQ_MODE_FULL3D && stage_no == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
+                    // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
+                    // accepted for randint(0, N) after it (the second is used when the first cell is occupied);
+                    // the uniform's two words follow the chosen triple.
+                    const uint32_t s = rng.pos & (RING - 1);
+                    const uint32_t vq = rng.view(rng.okq_lo, rng.okq_hi, s);
+                    const uint32_t pq = vq ? __builtin_ctz(vq) : 31u;
+                    const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << pq);
+                    const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
+                    if (vq && (n6 & 0x3fffffffu)) {
+                        const uint32_t p1 = __builtin_ctz(n1), p2 = __builtin_ctz(n2), p3 = __builtin_ctz(n3);
+                        const uint32_t p4 = __builtin_ctz(n4), p5 = __builtin_ctz(n5), p6 = __builtin_ctz(n6);
+                        const uint32_t wq = ring[(s + pq) & (RING - 1)];
+                        const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)], w3 = ring[(s + p3) & (RING - 1)];
+                        const uint32_t w4 = ring[(s + p4) & (RING - 1)], w5 = ring[(s + p5) & (RING - 1)], w6 = ring[(s + p6) & (RING - 1)];
+                        const uint32_t u31 = ring[(s + p3 + 1) & (RING - 1)], u32 = ring[(s + p3 + 2) & (RING - 1)];
+                        const uint32_t u61 = ring[(s + p6 + 1) & (RING - 1)], u62 = ring[(s + p6 + 2) & (RING - 1)];
+                        qi = (int)(wq & maskQ);
+                        oldp = qn[qi];
+                        const int i1 = (int)(w1 & maskN), j1 = (int)(w2 & maskN), k1 = (int)(w3 & maskN);
+                        const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN);
+                        const bool free1 = !((colw[__mul24(i1, N) + j1] >> k1) & 1u);
+                        const bool free2 = !((colw[__mul24(i2, N) + j2] >> k2) & 1u);
+                        pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
+                        uw1 = free1 ? u31 : u61, uw2 = free1 ? u32 : u62;
+                        if (free1 || free2) {
+                            rng.pos += (free1 ? p3 : p6) + 3;
                             break;
                         }
                     }
@@ -629,8 +674,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         } else if (stage_no == 3) {
                             if (okN) {
                                 pc = vN;
-                                const int f = (pa * N + pb) * N + pc;
-                                stage_no = ((occ[f >> 5] >> (f & 31)) & 1u) ? 1 : 4;  // occupied: draw the triple again
+                                stage_no = ((colw[pa * N + pb] >> pc) & 1u) ? 1 : 4;  // occupied: draw the triple again
                             }
                         } else if (stage_no == 4) {
                             uw1 = w, stage_no = 5;
@@ -684,19 +728,45 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
                 dE = group_sum<G>(acc) + 4;
             } else {
-                // every other queen against the old and the new cell (mcmc.py:185-226)
+                // conflicts_for_queen(q, new) - conflicts_for_queen(q) (mcmc.py:185-226) without visiting the queens:
+                // the 13 lines through a cell (ci,cj,ck) are the column itself plus, for every column (i2,j2) on the
+                // four lines of the ij-plane through (ci,cj) at distance d, the heights ck and ck +- d.  With W the
+                // occupancy word of that column, the attackers in it are popc(W & (B | B<<d | B>>d)), B = 1<<ck.
                 const int ni = pa, nj = pb, nk = pc;
-                newp = (uint32_t)ni | ((uint32_t)nj << 8) | ((uint32_t)nk << 16);
-                const int oi = oldp & 255, oj = (oldp >> 8) & 255, ok_ = (oldp >> 16) & 255;
+                const int oi = oldp & 31, oj = (oldp >> 5) & 31, ok_ = (oldp >> 10) & 31;
+                newp = (uint32_t)ni | ((uint32_t)nj << 5) | ((uint32_t)nk << 10);
+                const uint32_t Bo = 1u << ok_, Bn = 1u << nk;
+                auto star = [&](int m, bool in_board, int ci, int cj, uint32_t B) {
+                    const int mN_ = __mul24(m, N);
+                    const uint32_t* cw = colw + mN_;
+                    const int jd = m - ci + cj, ja = ci + cj - m;
+                    const uint32_t wr = colw[__mul24(ci, N) + m], wc = cw[cj], wd = cw[jd], wa = cw[ja];
+                    const uint32_t dr = abs_diff(m, cj), dc = abs_diff(m, ci);
+                    const uint32_t Mr = B | (B << dr) | (B >> dr), Mc = B | (B << dc) | (B >> dc);
+                    int c = __popc(wr & Mr) + __popc(wc & Mc);
+                    c += (unsigned)jd < (unsigned)N ? __popc(wd & Mc) : 0;  // out-of-board probes read padding or another column: discarded
+                    c += (unsigned)ja < (unsigned)N ? __popc(wa & Mc) : 0;
+                    return in_board ? c : 0;
+                };
                 int part = 0;
+                if constexpr (NT > 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const int m = gl + t * G;
+                        const bool in_board = t + 1 < NT || m < N;
+                        part += star(m, in_board, ni, nj, Bn) - star(m, in_board, oi, oj, Bo);
+                    }
+                } else {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int c = gl; c < Q; c += G) {
-                    const uint32_t pq = qn[c];
-                    const int ci = pq & 255, cj = (pq >> 8) & 255, ck = (pq >> 16) & 255;
-                    const int v = (int)on_a_line(ci - ni, cj - nj, ck - nk) - (int)on_a_line(ci - oi, cj - oj, ck - ok_);
-                    part += c != qi ? v : 0;
+                    for (int m = gl; m < N; m += G) part += star(m, true, ni, nj, Bn) - star(m, true, oi, oj, Bo);
                 }
-                dE = group_sum<G>(part);
+                // The old cell itself is probed once per planar direction (d = 0) and holds the moving queen: -4 on the old
+                // side, i.e. +4.  Own columns (the k-axis lines): popc(W) minus the moving queen on the old side.  On the
+                // new side the moving queen still sits at the old cell; if that lies on a line through the new cell it was
+                // counted and is removed.
+                const int own_new = __popc(colw[__mul24(ni, N) + nj]), own_old = __popc(colw[__mul24(oi, N) + oj]) - 1;
+                const int moving = on_a_line(oi - ni, oj - nj, ok_ - nk) ? 1 : 0;
+                dE = group_sum<G>(part) + 4 + own_new - own_old - moving;
             }
 
             // ---- accept iff u < min(1, exp(-beta dE)); the uniform is always drawn -------------------
@@ -724,13 +794,12 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 if (MODE == MCQ_MODE_BOARD) {
                     hts[cell] = (uint8_t)pc;  // every lane of the group writes the same byte
                 } else {
-                    const int fo = ((int)(oldp & 255) * N + (int)((oldp >> 8) & 255)) * N + (int)((oldp >> 16) & 255);
-                    const int fn = (pa * N + pb) * N + pc;
-                    if (gl == 0) {
-                        occ[fo >> 5] &= ~(1u << (fo & 31));
-                        occ[fn >> 5] |= 1u << (fn & 31);
-                    }
-                    qn[qi] = newp;
+                    // mcmc.py:171-183; every lane of the group performs the same read-modify-writes
+                    uint32_t* wo = colw + __mul24((int)(oldp & 31), N) + (int)((oldp >> 5) & 31);
+                    *wo &= ~(1u << ((oldp >> 10) & 31));
+                    uint32_t* wn = colw + __mul24(pa, N) + pb;
+                    *wn |= 1u << pc;
+                    qn[qi] = (uint16_t)newp;
                 }
                 E += dE;
                 n_acc++;
@@ -746,7 +815,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     } else {
                         for (int c = gl; c < Q; c += G) {
                             const uint32_t pq = qn[c];
-                            bo[3 * c] = (uint8_t)pq, bo[3 * c + 1] = (uint8_t)(pq >> 8), bo[3 * c + 2] = (uint8_t)(pq >> 16);
+                            bo[3 * c] = (uint8_t)(pq & 31), bo[3 * c + 1] = (uint8_t)((pq >> 5) & 31), bo[3 * c + 2] = (uint8_t)((pq >> 10) & 31);
                         }
                     }
                 }
@@ -801,7 +870,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             } else {
                 for (int c = gl; c < Q; c += G) {
                     const uint32_t pq = qn[c];
-                    fo[3 * c] = (uint8_t)pq, fo[3 * c + 1] = (uint8_t)(pq >> 8), fo[3 * c + 2] = (uint8_t)(pq >> 16);
+                    fo[3 * c] = (uint8_t)(pq & 31), fo[3 * c + 1] = (uint8_t)((pq >> 5) & 31), fo[3 * c + 2] = (uint8_t)((pq >> 10) & 31);
                 }
             }
         }
@@ -877,7 +946,7 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->rec_words = rec_words_for(p);
     // board: the diagonal probes read up to N-1 bytes before / after the heights; 8 spare words on each
     // side keep those (discarded) reads inside the chain's own LDS slice.
-    a->chain_lds_words = LDS_STATE + (p->mode == MCQ_MODE_BOARD ? 8 + (a->Q + 3) / 4 + 8 : a->Q + (p->N * p->N * p->N + 31) / 32);
+    a->chain_lds_words = LDS_STATE + (p->mode == MCQ_MODE_BOARD ? 8 + (a->Q + 3) / 4 + 8 : FULL_PAD + a->Q + FULL_PAD + (a->Q + 1) / 2);
     a->chain_lds_words = (a->chain_lds_words + 3) & ~3;  // 16-byte multiple: the staging block is read with ds_read_b128
     a->beta_const = p->beta_const, a->beta_start = p->beta_start, a->beta_end = p->beta_end;
     a->n_steps = p->n_steps, a->n_chains = p->n_chains;
@@ -955,7 +1024,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
 
-    const int G = p->lanes_per_chain ? p->lanes_per_chain : 4;
+    const int G = p->lanes_per_chain ? p->lanes_per_chain : mcq_default_lanes(p->mode);
     rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
@@ -975,6 +1044,8 @@ int mcq_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+int32_t mcq_default_lanes(int32_t mode) { return mode == MCQ_MODE_BOARD ? 4 : 8; }
 
 size_t mcq_state_bytes(int32_t N, int32_t mode) {
     if (N < MCQ_MIN_N || N > MCQ_MAX_N) return 0;
