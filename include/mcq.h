@@ -145,6 +145,20 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
                          size_t workspace_bytes, void* hip_stream, float* init_ms, float* sweep_ms);
 
 /*
+ * Statistics of a device-resident trace (what plot_energy_histories, experiments.py:593-595, and
+ * plot_acceptance_rates_binned, experiments.py:660-695, consume), so that the trace never crosses PCIe.
+ * `out` holds the DEVICE buffers a previous mcq_run_device filled.  All result arrays are device pointers:
+ *   step_sum / step_sumsq / step_count  int64[n_steps + 1]: over the chains whose history reaches that entry
+ *                                       (count < n_chains only after early stops); pass NULL to skip
+ *   bin_lo  int64[n_bins + 1]: first step of every bin (ascending, bin_lo[n_bins] >= n_steps closes the last);
+ *   bin_accepted / bin_proposed uint64[n_bins]: accepted / executed steps of all chains per bin; n_bins = 0 to skip
+ * Enqueued on `hip_stream`; asynchronous.
+ */
+int mcq_trace_stats_device(const mcq_params* p, const mcq_outputs* out, int64_t* step_sum, int64_t* step_sumsq,
+                           int64_t* step_count, int32_t n_bins, const int64_t* bin_lo, uint64_t* bin_accepted,
+                           uint64_t* bin_proposed, void* hip_stream);
+
+/*
  * Same computation with HOST buffers: allocates device memory, uploads seeds, runs,
  * downloads every non-NULL output and frees.  Blocking.  `kernel_seconds` (optional)
  * receives the device time of init + sweep measured with HIP events.

@@ -71,6 +71,9 @@ def lib():
         L.mcq_run_device_timed.restype = C.c_int
         L.mcq_run_device_timed.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.mcq_trace_stats_device.restype = C.c_int
+        L.mcq_trace_stats_device.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Outputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_run_host.restype = C.c_int
         L.mcq_run_host.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.POINTER(C.c_double)]
         if L.mcq_abi_version() != abi.ABI_VERSION:
@@ -161,6 +164,30 @@ class DeviceRun:
                                                self.ws_bytes, C.c_void_p(st.cuda_stream), C.byref(i_ms), C.byref(s_ms)))
         return i_ms.value, s_ms.value
 
+    def trace_stats(self, n_bins=100, stream=None):
+        """Per-step sum / sum of squares / count of the energy trace and binned accepted / proposed counts, computed on
+        the device from the resident trace (mcq_trace_stats_device).  Bin edges are those of the reference's
+        plot_acceptance_rates_binned: np.linspace(0, n_steps, n_bins + 1), left-closed (experiments.py:660-686).
+        Returns a dict of NumPy arrays (synchronises)."""
+        torch = self.torch
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        n = int(self.p.n_steps)
+        edges = np.linspace(0, n, n_bins + 1)
+        lo = np.ceil(edges).astype(np.int64)  # step s is in bin b iff edges[b] <= s < edges[b+1]  <=>  ceil(edges[b]) <= s < ceil(edges[b+1])
+        lo[-1] = max(n, int(lo[-1]))
+        with torch.cuda.device(self.device), torch.cuda.stream(st):
+            s_sum = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+            s_sq = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+            s_cnt = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+            b_lo = torch.from_numpy(lo).to(self.device)
+            b_acc = torch.zeros(n_bins, dtype=torch.int64, device=self.device)
+            b_pro = torch.zeros(n_bins, dtype=torch.int64, device=self.device)
+            _check(self.L.mcq_trace_stats_device(C.byref(self.p), C.byref(self.out), s_sum.data_ptr(), s_sq.data_ptr(), s_cnt.data_ptr(),
+                                                 n_bins, b_lo.data_ptr(), b_acc.data_ptr(), b_pro.data_ptr(), C.c_void_p(st.cuda_stream)))
+        st.synchronize()
+        return {"step_sum": s_sum.cpu().numpy(), "step_sumsq": s_sq.cpu().numpy(), "step_count": s_cnt.cpu().numpy(),
+                "bin_centers": (edges[:-1] + edges[1:]) / 2, "bin_accepted": b_acc.cpu().numpy(), "bin_proposed": b_pro.cpu().numpy()}
+
     def results(self):
         """Copy every output back as NumPy arrays (synchronises)."""
         res = {}
@@ -168,3 +195,24 @@ class DeviceRun:
             a = t.cpu().numpy()
             res[k] = a.view(np.uint64) if abi.OUTPUT_DTYPES[k] is np.uint64 else a
         return res
+
+
+def run_many(params_list, seeds_list, trace=True, states=False):
+    """Several parameter sets at once: every set gets its own device buffers and its own HIP stream, all
+    launches are enqueued back to back and run concurrently on the GPU (a set of 8 192 chains fills only
+    a fraction of an MI355X: BASELINE configs 4 and 5 are many such sets).  Returns ([result dict], seconds)
+    with `seconds` the wall time from the first enqueue to the last completion."""
+    import time
+
+    import torch
+
+    runs = [DeviceRun(p, s, trace=trace, states=states) for p, s in zip(params_list, seeds_list)]
+    streams = [torch.cuda.Stream() for _ in runs]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r, st in zip(runs, streams):
+        r.launch(stream=st)
+    for st in streams:
+        st.synchronize()
+    secs = time.perf_counter() - t0
+    return [r.results() for r in runs], secs

@@ -878,6 +878,63 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// trace statistics: what plot_energy_histories / plot_acceptance_rates_binned consume
+// (experiments.py:593-595 per-step mean/std over runs, 660-695 binned acceptance), computed from the
+// HBM-resident trace so that it never has to cross PCIe.
+// ------------------------------------------------------------------------------------------------
+// One workgroup per block of 64 history entries: thread (x = entry, y = chain slice) walks the chains,
+// reading 256-byte row segments (coalesced along x), and accumulates sum, sum of squares and count.
+__global__ __launch_bounds__(256) void mcq_step_stats_kernel(const int32_t* __restrict__ hist, const int64_t* __restrict__ hist_len,
+                                                             long long n_chains, long long hist_stride, long long n_entries,
+                                                             long long* __restrict__ sum, long long* __restrict__ sumsq,
+                                                             long long* __restrict__ count) {
+    __shared__ long long red[3][4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + x;
+    long long s = 0, q = 0, c = 0;
+    if (e < n_entries)
+        for (long long r = y; r < n_chains; r += 4) {
+            if (e < hist_len[r]) {  // ragged after an early stop
+                const long long v = hist[r * hist_stride + e];
+                s += v, q += v * v, c++;
+            }
+        }
+    red[0][y][x] = s, red[1][y][x] = q, red[2][y][x] = c;
+    __syncthreads();
+    if (y == 0 && e < n_entries) {
+        sum[e] = red[0][0][x] + red[0][1][x] + red[0][2][x] + red[0][3][x];
+        sumsq[e] = red[1][0][x] + red[1][1][x] + red[1][2][x] + red[1][3][x];
+        count[e] = red[2][0][x] + red[2][1][x] + red[2][2][x] + red[2][3][x];
+    }
+}
+
+// One thread per (chain, bin): accepted and proposed steps of the chain inside [bin_lo[b], bin_lo[b+1]).
+__global__ __launch_bounds__(256) void mcq_accept_bins_kernel(const unsigned long long* __restrict__ bits, const int64_t* __restrict__ executed,
+                                                              long long n_chains, long long bits_stride, int n_bins,
+                                                              const int64_t* __restrict__ bin_lo, unsigned long long* __restrict__ accepted,
+                                                              unsigned long long* __restrict__ proposed) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_chains * n_bins) return;
+    const long long r = t / n_bins;
+    const int b = (int)(t % n_bins);
+    const long long ex = executed[r];
+    long long lo = bin_lo[b], hi = bin_lo[b + 1];
+    if (hi > ex) hi = ex;
+    if (lo >= hi) return;
+    const unsigned long long* row = bits + r * bits_stride;
+    long long acc = 0;
+    for (long long w = lo >> 6; w <= (hi - 1) >> 6; w++) {
+        unsigned long long m = row[w];
+        const long long base = w << 6;
+        if (lo > base) m &= ~0ull << (lo - base);
+        if (hi < base + 64) m &= ~0ull >> (base + 64 - hi);
+        acc += __popcll(m);
+    }
+    atomicAdd(&accepted[b], (unsigned long long)acc);
+    atomicAdd(&proposed[b], (unsigned long long)(hi - lo));
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512];
@@ -1078,6 +1135,38 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     if (init_ms) *init_ms = a;
     if (sweep_ms) *sweep_ms = b;
     return rc;
+}
+
+int mcq_trace_stats_device(const mcq_params* p, const mcq_outputs* out, int64_t* step_sum, int64_t* step_sumsq, int64_t* step_count,
+                           int32_t n_bins, const int64_t* bin_lo, uint64_t* bin_accepted, uint64_t* bin_proposed, void* hip_stream) {
+    int rc = validate(p);
+    if (rc != MCQ_OK) return rc;
+    if (!out || !out->energy_hist || !out->accept_bits || !out->hist_len || !out->steps_executed)
+        return fail(MCQ_EINVAL, "trace statistics need energy_hist, accept_bits, hist_len and steps_executed");
+    if (p->hist_stride < p->n_steps + 1 || p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "stride too small");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const long long n_entries = p->n_steps + 1;
+    if (step_sum) {
+        if (!step_sumsq || !step_count) return fail(MCQ_EINVAL, "step_sum, step_sumsq and step_count go together");
+        hipLaunchKernelGGL(mcq_step_stats_kernel, dim3((unsigned)((n_entries + 63) / 64)), dim3(256), 0, s, out->energy_hist, out->hist_len,
+                           (long long)p->n_chains, (long long)p->hist_stride, n_entries, (long long*)step_sum, (long long*)step_sumsq,
+                           (long long*)step_count);
+        HIP_TRY(hipGetLastError());
+    }
+    if (n_bins > 0) {
+        if (!bin_lo || !bin_accepted || !bin_proposed) return fail(MCQ_EINVAL, "bin_lo, bin_accepted and bin_proposed go together");
+        HIP_TRY(hipMemsetAsync(bin_accepted, 0, (size_t)n_bins * 8, s));
+        HIP_TRY(hipMemsetAsync(bin_proposed, 0, (size_t)n_bins * 8, s));
+        const long long total = (long long)p->n_chains * n_bins;
+        if (total > 0) {
+            hipLaunchKernelGGL(mcq_accept_bins_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                               (const unsigned long long*)out->accept_bits, out->steps_executed, (long long)p->n_chains,
+                               (long long)p->bits_stride, (int)n_bins, bin_lo, (unsigned long long*)bin_accepted,
+                               (unsigned long long*)bin_proposed);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return MCQ_OK;
 }
 
 int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, double* kernel_seconds) {

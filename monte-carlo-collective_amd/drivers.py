@@ -26,6 +26,24 @@ def _runner_or_default(runner):
     return ex.run_chains if runner is None else runner
 
 
+def _run_all(runner, jobs, trace):
+    """Every job of a driver (one per beta pair / per (init_mode, N) cell).  On the GPU path the jobs are launched
+    concurrently on separate streams; an injected runner gets them one by one."""
+    prepared = []
+    for (N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience) in jobs:
+        if n_runs > 1:
+            if sp is None:
+                raise ValueError("schedule_params is required for parallel execution when n_runs > 1")
+        else:
+            patience = None  # the n_runs == 1 branch does not forward early_stop_patience (experiments.py:550-558)
+        prepared.append(dict(N=N, n_steps=n_steps, init_mode=init_mode, schedule_params=sp, seeds=ex.abi.seeds_for(base_seed, n_runs),
+                             mcmc_type=mcmc_type, early_stop_patience=patience))
+    if runner is None:
+        return ex.run_chains_many(prepared, trace=trace)[0]
+    return [runner(j["N"], j["n_steps"], j["init_mode"], j["schedule_params"], j["seeds"], mcmc_type=j["mcmc_type"],
+                   early_stop_patience=j["early_stop_patience"], trace=trace)[0] for j in prepared]
+
+
 def _run(runner, N, n_steps, init_mode, schedule_params, n_runs, base_seed, mcmc_type, early_stop_patience, trace):
     """run_experiment's semantics (experiments.py:475-573) on an arbitrary runner; returns the raw result dict."""
     if n_runs > 1:
@@ -47,6 +65,28 @@ def energy_statistics(all_histories):
         raise ValueError("histories have different lengths (early stop); per-step statistics are undefined")
     e = np.asarray(all_histories)
     return e.mean(axis=0), e.std(axis=0)
+
+
+def mean_std_from_sums(step_sum, step_sumsq, step_count):
+    """Per-step mean and population std from integer sums (the on-device statistics of a resident trace).
+    The mean equals np.mean of the int64 matrix bit for bit (all partial sums are exact in float64); the
+    std is computed from the exact integer numerator n*sum(x^2) - sum(x)^2 and agrees with NumPy's two-pass
+    formula to ~1e-15 relative."""
+    s = np.asarray(step_sum, dtype=np.int64)
+    q = np.asarray(step_sumsq, dtype=np.int64)
+    n = np.asarray(step_count, dtype=np.int64)
+    mean = s / n
+    num = np.array([int(ni) * int(qi) - int(si) * int(si) for ni, qi, si in zip(n, q, s)], dtype=object)
+    var = np.array([float(v) / (int(ni) * int(ni)) for v, ni in zip(num, n)], dtype=np.float64)
+    return mean, np.sqrt(np.maximum(var, 0.0))
+
+
+def acceptance_rates_from_bins(bin_accepted, bin_proposed):
+    """Rates per bin from the on-device counts; empty bins are NaN like the reference (experiments.py:690-693)."""
+    a = np.asarray(bin_accepted, dtype=np.float64)
+    p = np.asarray(bin_proposed, dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(p > 0, a / p, np.nan)
 
 
 def write_energy_csv(all_histories, label, out_dir="results"):
@@ -93,13 +133,14 @@ def run_beta_start_end_pairs(N, n_steps, beta_start_ends, annealing_type="linear
                              mcmc_type="full_3d", early_stop_patience=100000, runner=None):
     """experiments.py:741-846.  Returns {"all_histories": {label: [...]}, "all_best_energies": {label: [...]}}
     with label f"beta: {beta_start}->{beta_end}" (806)."""
-    runner = _runner_or_default(runner)
     all_histories, all_best, all_acc, all_rej = {}, {}, {}, {}
+    jobs, labels = [], []
     for idx, (beta_start, beta_end) in enumerate(beta_start_ends):
         sp = {"type": annealing_type, "beta_start": beta_start, "beta_end": beta_end}
         ex.build_schedule_from_params(annealing_type, n_steps, beta_start=beta_start, beta_end=beta_end)  # the reference's ValueErrors
-        res = _run(runner, N, n_steps, init_mode, sp, n_runs, base_seed + idx * 1000, mcmc_type, early_stop_patience, True)
-        label = f"beta: {beta_start}->{beta_end}"
+        jobs.append((N, n_steps, init_mode, sp, n_runs, base_seed + idx * 1000, mcmc_type, early_stop_patience))
+        labels.append(f"beta: {beta_start}->{beta_end}")
+    for label, res in zip(labels, _run_all(runner, jobs, True)):
         all_histories[label] = [res["energy_hist"][r, : int(res["hist_len"][r])] for r in range(n_runs)]
         all_best[label] = [int(b) for b in res["best_energy"]]
         if plot and out_path_acceptance is not None:
@@ -141,18 +182,21 @@ def measure_min_energy_vs_N(Ns, n_steps, beta_schedule, schedule_params=None, in
                             verbose=True, plot=True, out_path=None, mcmc_type="full_3d", early_stop_patience=100000,
                             runner=None):
     """experiments.py:1031-1201.  Histories are discarded by this experiment (1061), so no trace is produced."""
-    runner = _runner_or_default(runner)
     if isinstance(init_modes, str):
         init_modes = [init_modes]
     if schedule_params is None:
         schedule_params = getattr(beta_schedule, "params", None)
-    results = {}
+    jobs = []
     for init_mode in init_modes:
         offset = sum(ord(c) for c in init_mode) % 1000
-        all_min, all_stb = [], []
         for idx, N in enumerate(Ns):
-            res = _run(runner, N, n_steps, init_mode, schedule_params, n_runs, base_seed + 10 * idx + offset, mcmc_type,
-                       early_stop_patience, False)
+            jobs.append((N, n_steps, init_mode, schedule_params, n_runs, base_seed + 10 * idx + offset, mcmc_type, early_stop_patience))
+    all_res = iter(_run_all(runner, jobs, False))
+    results = {}
+    for init_mode in init_modes:
+        all_min, all_stb = [], []
+        for _N in Ns:
+            res = next(all_res)
             all_min.append(np.array([int(b) for b in res["best_energy"]]))
             all_stb.append(np.array([int(s) for s in res["steps_to_best"]]))
             if verbose:

@@ -175,6 +175,22 @@ def run_chains(N, n_steps, init_mode, schedule_params, seeds, mcmc_type="full_3d
     return _lib.run_host(params, seeds.astype(np.uint32), trace=trace, states=states)
 
 
+def run_chains_many(jobs, trace=True, states=False):
+    """Concurrent form of run_chains: `jobs` is a list of dicts with run_chains' arguments (N, n_steps, init_mode,
+    schedule_params, seeds, mcmc_type, early_stop_patience).  All jobs are enqueued on their own streams and
+    overlap on the GPU.  Returns ([result dict per job], seconds)."""
+    plist, slist = [], []
+    for j in jobs:
+        seeds = np.asarray(j["seeds"])
+        if seeds.size and (seeds.min() < 0 or seeds.max() > 2**32 - 1):
+            raise ValueError("Seed must be between 0 and 2**32 - 1")
+        plist.append(abi.make_params(j["N"], j["n_steps"], j["init_mode"], j["schedule_params"], len(seeds),
+                                     mcmc_type=j.get("mcmc_type", "full_3d"), early_stop_patience=j.get("early_stop_patience"),
+                                     trace=trace, lanes_per_chain=j.get("lanes_per_chain", 0)))
+        slist.append(seeds.astype(np.uint32))
+    return _lib.run_many(plist, slist, trace=trace, states=states)
+
+
 def accepted_rejected_steps(res, r):
     """Step indices of accepted / rejected proposals of chain r (experiments.py:329-332)."""
     n = int(res["steps_executed"][r])

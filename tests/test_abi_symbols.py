@@ -18,7 +18,7 @@ def _declared():
 def test_header_symbols_are_exported():
     names = _declared()
     hip = [n for n in names if not n.startswith("mcq_oracle")]
-    assert {"mcq_run_device", "mcq_run_device_timed", "mcq_default_lanes", "mcq_run_host", "mcq_workspace_bytes", "mcq_state_bytes", "mcq_abi_version",
+    assert {"mcq_run_device", "mcq_run_device_timed", "mcq_default_lanes", "mcq_trace_stats_device", "mcq_run_host", "mcq_workspace_bytes", "mcq_state_bytes", "mcq_abi_version",
             "mcq_last_error", "mcq_device_count"} <= set(hip)
     L = mcq_amd._lib.lib()
     for n in hip:

@@ -147,3 +147,32 @@ def test_errors_cross_the_abi_as_exceptions():
     p.sched = 9
     with pytest.raises(ValueError):
         mcq_amd._lib.run_host(p, abi.seeds_for(0, 2))
+
+
+def test_on_device_trace_statistics():
+    """mcq_trace_stats_device: per-step sums / counts and binned acceptance from the resident trace equal what
+    NumPy computes from the host copy (the reference's plot helpers, experiments.py:593-595, 660-695)."""
+    dr = mcq_amd.drivers
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    for patience, n_steps in ((None, 3333), (60, 1500)):
+        p = abi.make_params(8, n_steps, "random", sp, 77, mcmc_type="board", early_stop_patience=patience)
+        run = mcq_amd._lib.DeviceRun(p, abi.seeds_for(11, 77))
+        run.launch()
+        st = run.trace_stats(n_bins=100)
+        res = run.results()
+        L = res["hist_len"]
+        for e in (0, 1, 63, 64, n_steps // 2, n_steps):
+            col = np.array([res["energy_hist"][r, e] for r in range(77) if e < L[r]], dtype=np.int64)
+            assert st["step_count"][e] == len(col) and st["step_sum"][e] == col.sum() and st["step_sumsq"][e] == (col * col).sum()
+        steps = [mcq_amd.experiments.accepted_rejected_steps(res, r) for r in range(77)]
+        centers, rates = dr.acceptance_rates_binned([s[0] for s in steps], [s[1] for s in steps], n_steps, n_bins=100)
+        got = dr.acceptance_rates_from_bins(st["bin_accepted"], st["bin_proposed"])
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(rates))
+        np.testing.assert_allclose(got[~np.isnan(rates)], rates[~np.isnan(rates)], rtol=0, atol=0)
+        np.testing.assert_array_equal(st["bin_centers"], centers)
+        if patience is None:
+            hist = [res["energy_hist"][r, : L[r]] for r in range(77)]
+            mean, std = dr.energy_statistics(hist)
+            m2, s2 = dr.mean_std_from_sums(st["step_sum"], st["step_sumsq"], st["step_count"])
+            np.testing.assert_array_equal(m2, mean)
+            np.testing.assert_allclose(s2, std, rtol=1e-12)
