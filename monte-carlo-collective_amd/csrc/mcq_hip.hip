@@ -50,6 +50,29 @@ extern "C" int32_t mcq_default_lanes(int32_t mode);
 
 namespace {
 
+// Diagnostic build (-DMCQ_STAMPS, tools/stamp_profile.sh): s_memtime stamps around the sections of a Metropolis
+// step; the per-section cycle sums of every wavefront go to a debug buffer.  Never defined in the shipped library.
+#ifdef MCQ_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k)                                                        \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        st_acc[k] += st_now - st_prev;                                  \
+        st_prev = st_now;                                               \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#define STAMP_FLUSH(dbg)                                                      \
+    do {                                                                      \
+        if (threadIdx.x == 0)                                                 \
+            for (int k_ = 0; k_ < 8; k_++) atomicAdd(&(dbg)[k_], st_acc[k_]); \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH(dbg)
+#endif
+
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 constexpr int RING = 64;          // ready (tempered) words per chain
@@ -73,6 +96,7 @@ struct KArgs {
     float* c32_tab;         // [n_steps] (float)(-beta(step) * log2(e)): exp(-beta dE) = exp2(dE * c32)
     const uint32_t* seeds;
     mcq_outputs out;
+    unsigned long long* dbg;  // MCQ_STAMPS diagnostic build only: per-section cycle sums
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -564,8 +588,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)a.c32_tab;
     const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)a.beta_tab;
 
+    STAMP_DECL;
     const int n_steps = (int)a.n_steps;
     for (int vstep = 0; vstep < n_steps; vstep++) {
+        STAMP(0);  // loop overhead + previous step's tail
         // every live lane is at the same step; with early stopping the loop itself may become divergent
         const int step = PATIENCE ? __builtin_amdgcn_readfirstlane(vstep) : vstep;
         const float c32 = c32_tab[step];  // exp(-beta dE) = exp2(dE * c32)
@@ -582,110 +608,122 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             int stage_no = 0;
             // stream upkeep runs for every chain of the wavefront together: board steps use ~6.1 words, so one
             // block of 16 per two steps keeps up; full_3d steps use ~8.1, so every step
-            bool service = MODE == MCQ_MODE_BOARD ? (step & 1) == 0 : true;
-            for (;;) {
-                if (service) {
-                    if (rng.pending) rng.complete();
-                    // the block lands at the next upkeep, after >= 10 (board: two steps) or >= 6 (full_3d) more
-                    // words were consumed, or earlier only if the ring ran dry: there is room for its 16 words
-                    if (rng.gen - rng.pos <= (MODE == MCQ_MODE_BOARD ? 58u : 54u)) rng.issue();
-                }
-                service = true;  // a second pass means the ring ran dry: finish the block in flight now
-                if (MODE == MCQ_MODE_BOARD && stage_no == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
-                    // positions of the next four accepted words inside the 32 ring slots that follow pos
-                    const uint32_t s = rng.pos & (RING - 1);
-                    const uint32_t v1 = rng.view(rng.ok_lo, rng.ok_hi, s);
-                    const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1);
-                    if (v4 & 0x3fffffffu) {  // a fourth accepted word, and the two words of the uniform still inside the view
-                        const uint32_t p1 = __builtin_ctz(v1), p2 = __builtin_ctz(v2), p3 = __builtin_ctz(v3), p4 = __builtin_ctz(v4);
-                        const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)];
-                        const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)];
-                        pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
-                        const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN);
-                        cell = __mul24(pa, N) + pb;
-                        old_k = hts[cell];
-                        const bool use3 = c3 != old_k;
-                        pc = use3 ? c3 : c4;
-                        const uint32_t kp = use3 ? p3 : p4;
-                        uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
-                        if (pc != old_k) {
-                            rng.pos += kp + 3;
-                            break;
-                        }
-                    }
-                }
-                if (MODE == MCQ_MODE_FULL3D && stage_no == 0 && !force_slow && rng.gen - rng.pos >= 32u) {
-                    // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
-                    // accepted for randint(0, N) after it (the second is used when the first cell is occupied);
-                    // the uniform's two words follow the chosen triple.
-                    const uint32_t s = rng.pos & (RING - 1);
-                    const uint32_t vq = rng.view(rng.okq_lo, rng.okq_hi, s);
-                    const uint32_t pq = vq ? __builtin_ctz(vq) : 31u;
-                    const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << pq);
-                    const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
-                    if (vq && (n6 & 0x3fffffffu)) {
-                        const uint32_t p1 = __builtin_ctz(n1), p2 = __builtin_ctz(n2), p3 = __builtin_ctz(n3);
-                        const uint32_t p4 = __builtin_ctz(n4), p5 = __builtin_ctz(n5), p6 = __builtin_ctz(n6);
-                        const uint32_t wq = ring[(s + pq) & (RING - 1)];
-                        const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)], w3 = ring[(s + p3) & (RING - 1)];
-                        const uint32_t w4 = ring[(s + p4) & (RING - 1)], w5 = ring[(s + p5) & (RING - 1)], w6 = ring[(s + p6) & (RING - 1)];
-                        const uint32_t u31 = ring[(s + p3 + 1) & (RING - 1)], u32 = ring[(s + p3 + 2) & (RING - 1)];
-                        const uint32_t u61 = ring[(s + p6 + 1) & (RING - 1)], u62 = ring[(s + p6 + 2) & (RING - 1)];
-                        qi = (int)(wq & maskQ);
-                        oldp = qn[qi];
-                        const int i1 = (int)(w1 & maskN), j1 = (int)(w2 & maskN), k1 = (int)(w3 & maskN);
-                        const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN);
-                        const bool free1 = !((colw[__mul24(i1, N) + j1] >> k1) & 1u);
-                        const bool free2 = !((colw[__mul24(i2, N) + j2] >> k2) & 1u);
-                        pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
-                        uw1 = free1 ? u31 : u61, uw2 = free1 ? u32 : u62;
-                        if (free1 || free2) {
-                            rng.pos += (free1 ? p3 : p6) + 3;
-                            break;
-                        }
-                    }
-                }
-                // sequential: one word at a time from what the ring holds (nothing was consumed above)
-                while (rng.pos != rng.gen && stage_no < LAST) {
-                    const uint32_t w = ring[rng.pos & (RING - 1)];
-                    rng.pos++;
-                    const int vN = (int)(w & maskN);
-                    const bool okN = (unsigned)vN <= mN;
-                    if (MODE == MCQ_MODE_BOARD) {
-                        if (stage_no == 0) {
-                            if (okN) pa = vN, stage_no = 1;
-                        } else if (stage_no == 1) {
-                            if (okN) pb = vN, cell = pa * N + pb, old_k = hts[cell], stage_no = 2;
-                        } else if (stage_no == 2) {
-                            if (okN && vN != old_k) pc = vN, stage_no = 3;
-                        } else if (stage_no == 3) {
-                            uw1 = w, stage_no = 4;
-                        } else {
-                            uw2 = w, stage_no = 5;
-                        }
-                    } else {
-                        if (stage_no == 0) {
-                            const unsigned vQ = w & maskQ;
-                            if (vQ <= mQ) qi = (int)vQ, oldp = qn[qi], stage_no = 1;
-                        } else if (stage_no == 1) {
-                            if (okN) pa = vN, stage_no = 2;
-                        } else if (stage_no == 2) {
-                            if (okN) pb = vN, stage_no = 3;
-                        } else if (stage_no == 3) {
-                            if (okN) {
-                                pc = vN;
-                                stage_no = ((colw[pa * N + pb] >> pc) & 1u) ? 1 : 4;  // occupied: draw the triple again
+            auto upkeep = [&]() {
+                STAMP(0);
+                if (rng.pending) rng.complete();
+                // the block lands at the next upkeep, after >= 10 (board: two steps) or >= 6 (full_3d) more
+                // words were consumed, or earlier only if the ring ran dry: there is room for its 16 words
+                if (rng.gen - rng.pos <= (MODE == MCQ_MODE_BOARD ? 58u : 54u)) rng.issue();
+                STAMP(1);  // stream upkeep: complete + issue
+            };
+            // sequential draws: one word at a time from what the ring holds, topping it up when it runs dry
+            auto sequential = [&]() {
+                bool service = false;
+                for (;;) {
+                    if (service) upkeep();
+                    service = true;  // a second pass means the ring ran dry: finish the block in flight now
+                    while (rng.pos != rng.gen && stage_no < LAST) {
+                        const uint32_t w = ring[rng.pos & (RING - 1)];
+                        rng.pos++;
+                        const int vN = (int)(w & maskN);
+                        const bool okN = (unsigned)vN <= mN;
+                        if (MODE == MCQ_MODE_BOARD) {
+                            if (stage_no == 0) {
+                                if (okN) pa = vN, stage_no = 1;
+                            } else if (stage_no == 1) {
+                                if (okN) pb = vN, cell = pa * N + pb, old_k = hts[cell], stage_no = 2;
+                            } else if (stage_no == 2) {
+                                if (okN && vN != old_k) pc = vN, stage_no = 3;
+                            } else if (stage_no == 3) {
+                                uw1 = w, stage_no = 4;
+                            } else {
+                                uw2 = w, stage_no = 5;
                             }
-                        } else if (stage_no == 4) {
-                            uw1 = w, stage_no = 5;
                         } else {
-                            uw2 = w, stage_no = 6;
+                            if (stage_no == 0) {
+                                const unsigned vQ = w & maskQ;
+                                if (vQ <= mQ) qi = (int)vQ, oldp = qn[qi], stage_no = 1;
+                            } else if (stage_no == 1) {
+                                if (okN) pa = vN, stage_no = 2;
+                            } else if (stage_no == 2) {
+                                if (okN) pb = vN, stage_no = 3;
+                            } else if (stage_no == 3) {
+                                if (okN) {
+                                    pc = vN;
+                                    stage_no = ((colw[pa * N + pb] >> pc) & 1u) ? 1 : 4;  // occupied: draw the triple again
+                                }
+                            } else if (stage_no == 4) {
+                                uw1 = w, stage_no = 5;
+                            } else {
+                                uw2 = w, stage_no = 6;
+                            }
                         }
                     }
+                    if (stage_no == LAST) break;
                 }
-                if (stage_no == LAST) break;
+            };
+
+            if (MODE == MCQ_MODE_FULL3D || (step & 1) == 0) upkeep();
+            bool batched;  // the batched draw below succeeded for this chain
+            if constexpr (MODE == MCQ_MODE_BOARD) {
+                // Straight-line for every chain of the wavefront (no divergent branch): positions of the next four
+                // accepted words inside the 32 ring slots that follow pos, i / j / two candidates for new_k, the old
+                // height, and the uniform's two words behind the chosen candidate.  Where the attempt is not valid the
+                // fetched values are simply not used (every address is inside the chain's LDS slice).
+                const uint32_t s = rng.pos & (RING - 1);
+                const uint32_t v1 = rng.view(rng.ok_lo, rng.ok_hi, s);
+                const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1);
+                // a fourth accepted word with the two words of the uniform still inside the view, and a full view
+                const bool view_ok = (v4 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
+                const uint32_t top = 0x80000000u;  // keeps ctz defined when a mask is empty (view_ok is false then)
+                const uint32_t p1 = __builtin_ctz(v1 | top), p2 = __builtin_ctz(v2 | top), p3 = __builtin_ctz(v3 | top), p4 = __builtin_ctz(v4 | top);
+                const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)];
+                const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)];
+                pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
+                const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN);
+                cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
+                old_k = hts[cell];
+                const bool use3 = c3 != old_k;
+                pc = use3 ? c3 : c4;
+                const uint32_t kp = use3 ? p3 : p4;
+                uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
+                batched = view_ok && pc != old_k;  // both candidates equal to old_k (1/N^2): word by word instead
+                rng.pos += batched ? kp + 3 : 0u;
+            } else {
+                // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
+                // accepted for randint(0, N) after it (the second is used when the first cell is occupied);
+                // the uniform's two words follow the chosen triple.
+                const uint32_t s = rng.pos & (RING - 1);
+                const uint32_t top = 0x80000000u;
+                const uint32_t vq = rng.view(rng.okq_lo, rng.okq_hi, s);
+                const uint32_t pq = __builtin_ctz(vq | top);
+                const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << pq);
+                const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
+                const bool view_ok = vq != 0 && (n6 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
+                const uint32_t p1 = __builtin_ctz(n1 | top), p2 = __builtin_ctz(n2 | top), p3 = __builtin_ctz(n3 | top);
+                const uint32_t p4 = __builtin_ctz(n4 | top), p5 = __builtin_ctz(n5 | top), p6 = __builtin_ctz(n6 | top);
+                const uint32_t wq = ring[(s + pq) & (RING - 1)];
+                const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)], w3 = ring[(s + p3) & (RING - 1)];
+                const uint32_t w4 = ring[(s + p4) & (RING - 1)], w5 = ring[(s + p5) & (RING - 1)], w6 = ring[(s + p6) & (RING - 1)];
+                const uint32_t u31 = ring[(s + p3 + 1) & (RING - 1)], u32 = ring[(s + p3 + 2) & (RING - 1)];
+                const uint32_t u61 = ring[(s + p6 + 1) & (RING - 1)], u62 = ring[(s + p6 + 2) & (RING - 1)];
+                const uint32_t vqi = wq & maskQ;
+                qi = (int)(vqi <= mQ ? vqi : 0u);  // an unused attempt must still index inside the queen table
+                oldp = qn[qi];
+                const int i1 = (int)(w1 & maskN), j1 = (int)(w2 & maskN), k1 = (int)(w3 & maskN) & 31;
+                const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
+                const bool free1 = !((colw[__mul24(i1, N) + j1] >> k1) & 1u);  // word index < 2^10: inside the workgroup's LDS
+                const bool free2 = !((colw[__mul24(i2, N) + j2] >> k2) & 1u);
+                pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
+                uw1 = free1 ? u31 : u61, uw2 = free1 ? u32 : u62;
+                batched = view_ok && (free1 || free2);
+                rng.pos += batched ? (free1 ? p3 : p6) + 3 : 0u;
+            }
+            if (__any(!batched)) {  // wave-uniform guard of the rare path
+                if (!batched) sequential();
             }
 
+            STAMP(2);  // proposal draws
             // ---- dE -------------------------------------------------------------------------------
             int dE;
             uint32_t newp = 0;
@@ -769,6 +807,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 dE = group_sum<G>(part) + 4 + own_new - own_old - moving;
             }
 
+            STAMP(3);  // dE probes + reduce
             // ---- accept iff u < min(1, exp(-beta dE)); the uniform is always drawn -------------------
             // x = -beta dE < 0 iff beta and dE have the same sign (c32 has the sign of -beta); otherwise
             // the probability is 1 (also for a NaN beta, like min(1.0, nan) in the reference).
@@ -783,32 +822,32 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 acc = acc || sure_acc;
                 exact = xneg && !sure_acc && !sure_rej;
             }
-            if (exact) {
-                const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
-                acc = (r & 1) != 0, ties += r >> 1;
+            if (__any(exact)) {  // ~0.1 % of the steps of a chain
+                if (exact) {
+                    const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
+                    acc = (r & 1) != 0, ties += r >> 1;
+                }
             }
 
-            bool improved = false;
-            if (acc) {
-                accw |= 1u << (step & 31);
-                if (MODE == MCQ_MODE_BOARD) {
-                    hts[cell] = (uint8_t)pc;  // every lane of the group writes the same byte
-                } else {
-                    // mcmc.py:171-183; every lane of the group performs the same read-modify-writes
-                    uint32_t* wo = colw + __mul24((int)(oldp & 31), N) + (int)((oldp >> 5) & 31);
-                    *wo &= ~(1u << ((oldp >> 10) & 31));
-                    uint32_t* wn = colw + __mul24(pa, N) + pb;
-                    *wn |= 1u << pc;
-                    qn[qi] = (uint16_t)newp;
-                }
-                E += dE;
-                n_acc++;
-                improved = E < best;
+            STAMP(4);  // accept test
+            accw |= acc ? 1u << (step & 31) : 0u;
+            if (MODE == MCQ_MODE_BOARD) {
+                hts[cell] = (uint8_t)(acc ? pc : old_k);  // every lane of the group writes the same byte; a rejected move rewrites the old height
+            } else if (acc) {
+                // mcmc.py:171-183; every lane of the group performs the same read-modify-writes
+                uint32_t* wo = colw + __mul24((int)(oldp & 31), N) + (int)((oldp >> 5) & 31);
+                *wo &= ~(1u << ((oldp >> 10) & 31));
+                uint32_t* wn = colw + __mul24(pa, N) + pb;
+                *wn |= 1u << pc;
+                qn[qi] = (uint16_t)newp;
             }
+            E += acc ? dE : 0;
+            n_acc += acc ? 1 : 0;
+            const bool improved = acc && E < best;
+            best = improved ? E : best;
             if (PATIENCE) no_imp = improved ? 0 : no_imp + 1;
-            if (improved) {
-                best = E;
-                if (a.out.best_state) {
+            if (__any(improved) && a.out.best_state) {  // rare after the first few hundred steps
+                if (improved) {
                     uint8_t* bo = a.out.best_state + chain * (long long)a.state_bytes;
                     if (MODE == MCQ_MODE_BOARD) {
                         for (int c = gl; c < Q; c += G) bo[c] = hts[c];
@@ -832,7 +871,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 if (bits && gl == 0) bits[step >> 5] = accw;
             } else {
                 stage[e & 15] = (uint32_t)E;
-                if (improved) best_step = e;
+                best_step = improved ? e : best_step;
                 if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
                     if constexpr (WPL == 4) *(uint4*)(hist + e - 15) = *(const uint4*)(stage + gl * 4);
                     else if constexpr (WPL == 2) *(uint2*)(hist + e - 15) = *(const uint2*)(stage + gl * 2);
@@ -844,8 +883,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             }
         }
+        STAMP(5);  // apply + history
         if (PATIENCE && !__any(active)) break;
     }
+    STAMP_FLUSH(a.dbg);
 
     if (active) {  // ran to n_steps: flush the partial last block and word
         if (trace && (n_steps & 15) != 15)
@@ -938,6 +979,9 @@ __global__ __launch_bounds__(256) void mcq_accept_bins_kernel(const unsigned lon
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512];
+#ifdef MCQ_STAMPS
+unsigned long long* g_dbg = nullptr;
+#endif
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -1013,6 +1057,9 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->c32_tab = (float*)((char*)ws + beta_tab_bytes(p));
     a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p));
     a->seeds = seeds, a->out = *out;
+#ifdef MCQ_STAMPS
+    a->dbg = g_dbg;
+#endif
     if (p->trace == MCQ_TRACE_NONE) a->out.energy_hist = nullptr, a->out.accept_bits = nullptr;
     return MCQ_OK;
 }
@@ -1123,7 +1170,22 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
                          size_t workspace_bytes, void* hip_stream, float* init_ms, float* sweep_ms) {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+#ifdef MCQ_STAMPS
+    if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 64));
+    HIP_TRY(hipMemset(g_dbg, 0, 64));
+#endif
     int rc = run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, ev);
+#ifdef MCQ_STAMPS
+    if (rc == MCQ_OK) {
+        unsigned long long h[8];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h, g_dbg, 64, hipMemcpyDeviceToHost));
+        const char* names[8] = {"loop", "stream_upkeep", "draws", "dE", "accept", "apply+history", "-", "-"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 6; k++) tot += h[k];
+        for (int k = 0; k < 6; k++) fprintf(stderr, "STAMP %-14s %14llu  %5.1f %%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
+    }
+#endif
     float a = 0.f, b = 0.f;
     if (rc == MCQ_OK) {
         hipError_t e = hipEventSynchronize(ev[2]);

@@ -222,6 +222,38 @@ def measure_min_energy_vs_N(Ns, n_steps, beta_schedule, schedule_params=None, in
     return {"Ns": Ns, "results": results}
 
 
+def write_best_heights(heights, N, path):
+    """competition.py:179-187: the best board as one `i,j,k` line per column (row-major)."""
+    h = np.asarray(heights).reshape(N, N)
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w") as f:
+        for i in range(N):
+            for j in range(N):
+                f.write(f"{i},{j},{int(h[i, j])}\n")
+    return path
+
+
+def run_competition(N=15, n_runs=10, n_steps=100000, beta_start=1.0, beta_end=3.0, base_seed=42, init_mode="random",
+                    out_dir="competition_results", runner=None, timestamp=None):
+    """competition.py:143-187: board chains with linear annealing beta_start -> beta_end, seeds base_seed + r; the board
+    of the run with the lowest best energy is written to {out_dir}/best_heights_{N}_{timestamp}.txt.
+    Returns (best energy, heights, path)."""
+    import time
+
+    runner = _runner_or_default(runner)
+    sp = {"type": "linear_annealing", "beta_start": beta_start, "beta_end": beta_end}
+    try:
+        res, _ = runner(N, n_steps, init_mode, sp, ex.abi.seeds_for(base_seed, n_runs), mcmc_type="board", early_stop_patience=None,
+                        trace=False, states=True)
+    except TypeError:  # injected runners without a `states` argument return the states anyway
+        res, _ = runner(N, n_steps, init_mode, sp, ex.abi.seeds_for(base_seed, n_runs), mcmc_type="board", early_stop_patience=None, trace=False)
+    r = int(np.argmin(res["best_energy"]))  # first run with the minimum, like min() over the runs in order
+    heights = np.asarray(res["best_state"][r]).reshape(N, N)
+    stamp = timestamp if timestamp is not None else time.strftime("%Y%m%d_%H%M%S")
+    path = write_best_heights(heights, N, os.path.join(out_dir, f"best_heights_{N}_{stamp}.txt"))
+    return int(res["best_energy"][r]), heights, path
+
+
 def load_config(path="config.yaml"):
     """The reference's config.yaml (config.yaml:1-37); key names verbatim, including `betta_scheduling`."""
     import yaml

@@ -98,6 +98,25 @@ def test_config_dispatch_and_csv(tmp_path, monkeypatch):
         dr.run_compare_beta_end([4], 10, [[1, 2]], runner=oracle_runner)
 
 
+def test_competition_writer(tmp_path):
+    def runner(N, n_steps, init_mode, sp, seeds, mcmc_type="board", early_stop_patience=None, trace=False):
+        p = abi.make_params(N, n_steps, init_mode, sp, len(seeds), mcmc_type=mcmc_type, trace=trace)
+        return oracle.run(p, np.asarray(seeds, dtype=np.uint32), trace=trace, states=True), 0.0
+
+    best, heights, path = dr.run_competition(N=7, n_runs=5, n_steps=800, base_seed=42, out_dir=str(tmp_path), runner=runner, timestamp="t")
+    lines = open(path).read().split()
+    assert path.endswith("best_heights_7_t.txt") and len(lines) == 49 and lines[0].startswith("0,0,") and lines[-1].startswith("6,6,")
+    # the written board really has the reported energy: recount attacking pairs from the file
+    cells = [tuple(int(v) for v in ln.split(",")) for ln in lines]
+    e = 0
+    for a in range(49):
+        for b in range(a + 1, 49):
+            d = [abs(cells[a][t] - cells[b][t]) for t in range(3)]
+            nz = [x for x in d if x]
+            e += len(set(nz)) == 1
+    assert e == best
+
+
 def test_ragged_histories_are_rejected_explicitly():
     with pytest.raises(ValueError):
         dr.energy_statistics([np.arange(5), np.arange(4)])
