@@ -672,22 +672,28 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 // fetched values are simply not used (every address is inside the chain's LDS slice).
                 const uint32_t s = rng.pos & (RING - 1);
                 const uint32_t v1 = rng.view(rng.ok_lo, rng.ok_hi, s);
-                const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1);
-                // a fourth accepted word with the two words of the uniform still inside the view, and a full view
-                const bool view_ok = (v4 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
+                const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
+                // a fifth accepted word with the two words of the uniform still inside the view, and a full view
+                const bool view_ok = (v5 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
                 const uint32_t top = 0x80000000u;  // keeps ctz defined when a mask is empty (view_ok is false then)
-                const uint32_t p1 = __builtin_ctz(v1 | top), p2 = __builtin_ctz(v2 | top), p3 = __builtin_ctz(v3 | top), p4 = __builtin_ctz(v4 | top);
+                const uint32_t p1 = __builtin_ctz(v1 | top), p2 = __builtin_ctz(v2 | top), p3 = __builtin_ctz(v3 | top);
+                const uint32_t p4 = __builtin_ctz(v4 | top), p5 = __builtin_ctz(v5 | top);
                 const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)];
-                const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)];
+                const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)], w5 = ring[(s + p5) & (RING - 1)];
+                // the uniform's two words follow whichever candidate becomes new_k: all three pairs are requested now, so
+                // that nothing has to wait for the old height (one LDS round trip less on the step's critical path)
+                const uint32_t u31 = ring[(s + p3 + 1) & (RING - 1)], u32 = ring[(s + p3 + 2) & (RING - 1)];
+                const uint32_t u41 = ring[(s + p4 + 1) & (RING - 1)], u42 = ring[(s + p4 + 2) & (RING - 1)];
+                const uint32_t u51 = ring[(s + p5 + 1) & (RING - 1)], u52 = ring[(s + p5 + 2) & (RING - 1)];
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
-                const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN);
+                const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN), c5 = (int)(w5 & maskN);
                 cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
                 old_k = hts[cell];
-                const bool use3 = c3 != old_k;
-                pc = use3 ? c3 : c4;
-                const uint32_t kp = use3 ? p3 : p4;
-                uw1 = ring[(s + kp + 1) & (RING - 1)], uw2 = ring[(s + kp + 2) & (RING - 1)];
-                batched = view_ok && pc != old_k;  // both candidates equal to old_k (1/N^2): word by word instead
+                const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
+                pc = use3 ? c3 : use4 ? c4 : c5;
+                const uint32_t kp = use3 ? p3 : use4 ? p4 : p5;
+                uw1 = use3 ? u31 : use4 ? u41 : u51, uw2 = use3 ? u32 : use4 ? u42 : u52;
+                batched = view_ok && pc != old_k;  // three candidates in a row equal to old_k (1/N^3): word by word instead
                 rng.pos += batched ? kp + 3 : 0u;
             } else {
                 // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
