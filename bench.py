@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICR
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=int(os.environ.get("WORLD_SIZE", "1")))
     ap.add_argument("--steps", type=int, default=3, help="timed launches (K)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed launches (W)")
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
@@ -59,13 +59,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    # one rank per GPU; MCQ_BENCH_BACKEND=gloo (testing only) lets several ranks share a GPU and reduces on the host
+    backend = os.environ.get("MCQ_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     if args.schedule == "constant":
         sp = {"type": "constant", "beta_const": 5.0}
@@ -85,6 +92,7 @@ def main():
         mn = run.t["best_energy"].min().to(torch.int64).reshape(1)
         sm = torch.stack([run.t["n_accepted"].sum(), run.t["steps_executed"].sum(), run.t["best_energy"].to(torch.int64).sum()])
         if dist is not None:
+            mn, sm = mn.to(red_dev), sm.to(red_dev)
             dist.all_reduce(mn, op=dist.ReduceOp.MIN)
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         return mn, sm
@@ -110,7 +118,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 

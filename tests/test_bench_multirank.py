@@ -1,0 +1,39 @@
+"""bench.py under torch.distributed.run with two ranks sharing the one GPU (gloo override for the summary
+reduce): the multi-rank code path -- process group, barriers, MIN/SUM all-reduce, max-over-ranks timing,
+rank-0 JSON line -- and the fact that the job's results do not depend on how the chains are sharded."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, launcher, chains):
+    env = dict(os.environ, **extra_env)
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--n-steps", "3000", "--chains", str(chains),
+                      "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_equal_one_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    one = _bench({}, [sys.executable], 8192)
+    two = _bench({"MCQ_BENCH_BACKEND": "gloo"},
+                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(port)], 4096)
+    two_gpus = two.pop("n_gpus")
+    assert two_gpus == 2 and one["n_gpus"] == 1
+    assert two["config"]["chains_total"] == one["config"]["chains_total"] == 8192
+    for k in ("min_energy", "mean_best_energy", "acceptance_rate"):  # same 8192 chains, same seeds, however they are split
+        assert two[k] == one[k], k
+    assert two["scaling"] == "weak" and two["unit"] == "moves/s" and two["value"] > 0
