@@ -61,6 +61,7 @@ extern "C" {
 /* energy_history trace */
 #define MCQ_TRACE_NONE 0 /* only per-chain summaries (measure_min_energy_vs_N discards histories: experiments.py:1061) */
 #define MCQ_TRACE_I32 1  /* full int32 trace + accept bits (experiments.py:355, 329-332) */
+#define MCQ_TRACE_REDUCED 2 /* no per-chain trace: per-entry sums over the chains (what the plots consume, experiments.py:593-595, 660-695) */
 
 /* flags */
 #define MCQ_FLAG_EXACT_EXP 1u        /* evaluate exp(-beta*dE) in float64 on every step (disable the float32 bracket) */
@@ -110,6 +111,11 @@ typedef struct mcq_outputs {
     int64_t* near_ties;      /* optional [n_chains]: steps whose uniform fell within 4 ulp of the acceptance probability */
     uint8_t* best_state;     /* optional [n_chains][state_bytes] */
     uint8_t* final_state;    /* optional [n_chains][state_bytes] */
+    /* trace == REDUCED only, int64[n_steps + 1] each, indexed by history entry e (entry 0 = initial state): */
+    int64_t* step_sum;       /* sum over chains of energy_history[e]                                   */
+    int64_t* step_sumsq;     /* sum of squares                                                         */
+    int64_t* step_accepted;  /* chains whose step e - 1 was accepted (entry 0: 0)                       */
+    int64_t* step_count;     /* chains whose history has entry e (< n_chains only after early stops)    */
 } mcq_outputs;
 
 /* ---- exported by libmcq_hip.so ------------------------------------------------------------ */

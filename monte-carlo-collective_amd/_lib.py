@@ -104,7 +104,7 @@ def run_host(params, seeds, trace=True, states=True):
     if seeds.shape != (params.n_chains,):
         raise ValueError("seeds must have one entry per chain")
     p = abi.Params.from_buffer_copy(params)
-    p.trace = abi.TRACE_I32 if trace else abi.TRACE_NONE
+    p.trace = abi.trace_mode(trace)
     arrays = {k: np.zeros(shape, dtype=abi.OUTPUT_DTYPES[k])
               for k, shape in abi.output_shapes(p, trace=trace, states=states).items()}
     out = abi.Outputs()
@@ -127,7 +127,7 @@ class DeviceRun:
         self.torch = torch
         self.L = lib()
         self.p = abi.Params.from_buffer_copy(params)
-        self.p.trace = abi.TRACE_I32 if trace else abi.TRACE_NONE
+        self.p.trace = abi.trace_mode(trace)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         tdt = {np.int32: torch.int32, np.int64: torch.int64, np.uint8: torch.uint8, np.uint64: torch.int64}
         self.t = {}

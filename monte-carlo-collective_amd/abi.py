@@ -22,7 +22,7 @@ SCHED = {
     "sinusoidal_annealing": 4,
 }
 RNG_MT19937_NUMPY = 0
-TRACE_NONE, TRACE_I32 = 0, 1
+TRACE_NONE, TRACE_I32, TRACE_REDUCED = 0, 1, 2
 FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
 
@@ -66,6 +66,10 @@ class Outputs(C.Structure):
         ("near_ties", C.c_void_p),
         ("best_state", C.c_void_p),
         ("final_state", C.c_void_p),
+        ("step_sum", C.c_void_p),
+        ("step_sumsq", C.c_void_p),
+        ("step_accepted", C.c_void_p),
+        ("step_count", C.c_void_p),
     ]
 
 
@@ -83,6 +87,10 @@ OUTPUT_DTYPES = {
     "near_ties": np.int64,
     "best_state": np.uint8,
     "final_state": np.uint8,
+    "step_sum": np.int64,
+    "step_sumsq": np.int64,
+    "step_accepted": np.int64,
+    "step_count": np.int64,
 }
 
 
@@ -106,7 +114,10 @@ def output_shapes(p, trace=True, states=True):
     n = p.n_chains
     shapes = {k: (n,) for k in ("hist_len", "steps_executed", "initial_energy", "best_energy", "final_energy",
                                 "steps_to_best", "n_accepted", "near_ties")}
-    if trace:
+    if isinstance(trace, str) and trace == "reduced":
+        for k in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+            shapes[k] = (p.n_steps + 1,)
+    elif trace:
         shapes["energy_hist"] = (n, p.hist_stride)
         shapes["accept_bits"] = (n, p.bits_stride)
     if states:
@@ -114,6 +125,13 @@ def output_shapes(p, trace=True, states=True):
         shapes["best_state"] = (n, sb)
         shapes["final_state"] = (n, sb)
     return shapes
+
+
+def trace_mode(trace):
+    """True / False / "reduced" -> MCQ_TRACE_*"""
+    if trace == "reduced":
+        return TRACE_REDUCED
+    return TRACE_I32 if trace else TRACE_NONE
 
 
 def mode_of(mcmc_type):
@@ -162,7 +180,7 @@ def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="ful
     p.init = INIT[init_mode]
     p.sched = SCHED[st]
     p.rng = RNG_MT19937_NUMPY
-    p.trace = TRACE_I32 if trace else TRACE_NONE
+    p.trace = trace_mode(trace)
     p.flags = flags
     p.beta_const = float(bc) if bc is not None else 0.0
     p.beta_start = float(bs) if bs is not None else 0.0

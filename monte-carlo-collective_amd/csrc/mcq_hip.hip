@@ -76,6 +76,7 @@ namespace {
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 constexpr int RING = 64;          // ready (tempered) words per chain
+constexpr int RED_STRIPES = 8;    // trace == REDUCED: independent accumulator copies, so one address sees few atomics
 constexpr int REC_POS = 624;      // record word: MT index of the next word to consume
 constexpr int REC_GEN_END = 625;  // record word: words [0, gen_end) belong to the current generation
 constexpr int REC_E0 = 626;       // record word: initial energy
@@ -96,6 +97,8 @@ struct KArgs {
     float* c32_tab;         // [n_steps] (float)(-beta(step) * log2(e)): exp(-beta dE) = exp2(dE * c32)
     const uint32_t* seeds;
     mcq_outputs out;
+    unsigned long long* red;  // trace == REDUCED: [RED_STRIPES][4][red_len] per-entry sums (E, E^2, accepted, chains)
+    long long red_len;
     unsigned long long* dbg;  // MCQ_STAMPS diagnostic build only: per-section cycle sums
 };
 
@@ -514,9 +517,52 @@ constexpr int LDS_STAGE = RING;            // word offset of the energy_history 
 constexpr int LDS_STATE = RING + 16;       // word offset of the state
 constexpr int FULL_PAD = 32;               // full_3d: spare words on either side of the column words (N <= 32)
 
+// trace == REDUCED: add the block of 16 history entries [e0, e0 + 16) of the wavefront's chains to the per-entry
+// accumulators.  A stage word is E | accepted << 31; entry e of a chain counts iff e < hist_len (chains that stopped
+// early, and the idle groups of the last wavefront, drop out by that rule).  Every lane of the wavefront takes part.
+template <int G>
+__device__ __forceinline__ void reduce_block(const uint32_t* stage, int gl, int grp, int e0, int hist_len, unsigned long long* red,
+                                             long long red_len) {
+    constexpr int WPL = 16 / G;
+#pragma unroll
+    for (int w = 0; w < WPL; w++) {
+        const int idx = e0 + gl * WPL + w;
+        const uint32_t x = stage[gl * WPL + w];
+        const bool valid = idx < hist_len;
+        uint32_t se = valid ? x & 0x7fffffffu : 0u;                       // sum of E
+        unsigned long long sq = (unsigned long long)se * se;              // sum of E^2
+        uint32_t ac = valid ? (x >> 31) | 0x10000u : 0u;                  // accepted count | chains << 16
+        for (int off = G; off < 64; off <<= 1) {                          // over the 64 / G chains of the wavefront
+            se += (uint32_t)__shfl_xor((int)se, off, 64);
+            ac += (uint32_t)__shfl_xor((int)ac, off, 64);
+            sq += ((unsigned long long)(uint32_t)__shfl_xor((int)(sq >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sq, off, 64);
+        }
+        if (grp == 0 && (ac >> 16) != 0) {
+            atomicAdd(red + idx, (unsigned long long)se);
+            atomicAdd(red + red_len + idx, sq);
+            atomicAdd(red + 2 * red_len + idx, (unsigned long long)(ac & 0xffffu));
+            atomicAdd(red + 3 * red_len + idx, (unsigned long long)(ac >> 16));
+        }
+    }
+}
+
+// sum of the stripes -> the caller's arrays
+__global__ __launch_bounds__(256) void mcq_reduced_finalize_kernel(const unsigned long long* __restrict__ red, long long red_len, long long n_entries,
+                                                                   long long* __restrict__ sum, long long* __restrict__ sumsq,
+                                                                   long long* __restrict__ accepted, long long* __restrict__ count) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries) return;
+    unsigned long long t[4] = {0, 0, 0, 0};
+    for (int st = 0; st < RED_STRIPES; st++)
+        for (int k = 0; k < 4; k++) t[k] += red[((long long)st * 4 + k) * red_len + e];
+    sum[e] = (long long)t[0], sumsq[e] = (long long)t[1], accepted[e] = (long long)t[2], count[e] = (long long)t[3];
+}
+
 // NT > 0: ceil(N / G) is a compile-time constant, so the dE probes of a step are issued as one straight-line block
 // (all their LDS reads in flight together); NT == 0: run-time loop over the probe passes.
-template <int MODE, int G, bool PATIENCE, int NT>
+// REDUCED: trace == MCQ_TRACE_REDUCED (per-entry sums accumulated in the sweep); a separate instantiation so that the
+// default kernels carry none of its code.
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED>
 __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
@@ -527,7 +573,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     const long long chain = (long long)blockIdx.x * CPW + grp;
     const int N = a.N, Q = a.Q;
     bool active = chain < a.n_chains;
-    if (!PATIENCE && !active) return;  // no wave-wide operation below: idle groups of the last wavefront can leave
+    constexpr bool reduced = REDUCED;
+    if (!PATIENCE && !active && !reduced) return;  // no wave-wide operation below: idle groups of the last wavefront can leave
     const long long crow = active ? chain : 0;
 
     uint32_t* base = lds + grp * a.chain_lds_words;
@@ -563,7 +610,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
-    int hist_len = (int)a.n_steps + 1;
+    int hist_len = active ? (int)a.n_steps + 1 : 0;
+    unsigned long long* red = reduced ? a.red + (long long)(blockIdx.x & (RED_STRIPES - 1)) * 4 * a.red_len : nullptr;
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
@@ -590,6 +638,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
+    int last_entry = n_steps;  // wave-uniform: the last history entry any chain of the wavefront can have reached
     for (int vstep = 0; vstep < n_steps; vstep++) {
         STAMP(0);  // loop overhead + previous step's tail
         // every live lane is at the same step; with early stopping the loop itself may become divergent
@@ -876,7 +925,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         if (gl * WPL + w <= (step & 15)) hist[(step & ~15) + w] = (int)stage[gl * WPL + w];
                 if (bits && gl == 0) bits[step >> 5] = accw;
             } else {
-                stage[e & 15] = (uint32_t)E;
+                stage[e & 15] = (uint32_t)E | (reduced && acc ? 0x80000000u : 0u);  // bit 31: this entry's step was accepted
                 best_step = improved ? e : best_step;
                 if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
                     if constexpr (WPL == 4) *(uint4*)(hist + e - 15) = *(const uint4*)(stage + gl * 4);
@@ -890,9 +939,14 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             }
         }
         STAMP(5);  // apply + history
-        if (PATIENCE && !__any(active)) break;
+        if (reduced && ((step + 1) & 15) == 15) reduce_block<G>(stage, gl, grp, (step + 1) & ~15, hist_len, red, a.red_len);
+        if (PATIENCE && !__any(active)) {
+            last_entry = step + 1;
+            break;
+        }
     }
     STAMP_FLUSH(a.dbg);
+    if (reduced && (last_entry & 15) != 15) reduce_block<G>(stage, gl, grp, last_entry & ~15, hist_len, red, a.red_len);  // partial last block
 
     if (active) {  // ran to n_steps: flush the partial last block and word
         if (trace && (n_steps & 15) != 15)
@@ -1022,7 +1076,7 @@ int validate(const mcq_params* p) {
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL) return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
     if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "unknown rng");
-    if (p->trace != MCQ_TRACE_NONE && p->trace != MCQ_TRACE_I32) return fail(MCQ_EINVAL, "unknown trace mode");
+    if (p->trace != MCQ_TRACE_NONE && p->trace != MCQ_TRACE_I32 && p->trace != MCQ_TRACE_REDUCED) return fail(MCQ_EINVAL, "unknown trace mode");
     if (p->n_steps < 0 || p->n_steps > 2147483000LL) return fail(MCQ_EINVAL, "n_steps out of range [0, 2^31)");
     if (p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_chains");
     if (p->lanes_per_chain != 0 && p->lanes_per_chain != 4 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
@@ -1035,6 +1089,8 @@ int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_by
 
 size_t beta_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 8 + 255) & ~(size_t)255; }
 size_t c32_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 4 + 255) & ~(size_t)255; }
+long long red_len_for(const mcq_params* p) { return (p->n_steps + 1 + 31) & ~31LL; }
+size_t red_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 4 * red_len_for(p) * 8 : 0; }
 
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
     memset(a, 0, sizeof *a);
@@ -1061,23 +1117,25 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->hist_stride = p->hist_stride, a->bits_stride = p->bits_stride;
     a->beta_tab = (double*)ws;
     a->c32_tab = (float*)((char*)ws + beta_tab_bytes(p));
-    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p));
+    a->red = p->trace == MCQ_TRACE_REDUCED ? (unsigned long long*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p)) : nullptr;
+    a->red_len = red_len_for(p);
+    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p));
     a->seeds = seeds, a->out = *out;
 #ifdef MCQ_STAMPS
     a->dbg = g_dbg;
 #endif
-    if (p->trace == MCQ_TRACE_NONE) a->out.energy_hist = nullptr, a->out.accept_bits = nullptr;
+    if (p->trace != MCQ_TRACE_I32) a->out.energy_hist = nullptr, a->out.accept_bits = nullptr;
     return MCQ_OK;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED>
 int launch_sweep(const KArgs& a, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -1085,13 +1143,14 @@ int launch_sweep(const KArgs& a, hipStream_t s) {
 template <int MODE, int G>
 int launch_sweep_g(const KArgs& a, hipStream_t s) {
     const bool pat = MODE == MCQ_MODE_BOARD && a.patience >= 0;
+    if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
     if (MODE == MCQ_MODE_BOARD && G == 4 && !pat) {  // straight-line probe blocks for the common board sizes
         const int nt = (a.N + G - 1) / G;
-        if (nt == 3) return launch_sweep<MODE, G, false, 3>(a, s);  // N = 9..12
-        if (nt == 4) return launch_sweep<MODE, G, false, 4>(a, s);  // N = 13..16
-        if (nt == 6) return launch_sweep<MODE, G, false, 6>(a, s);  // N = 21..24
+        if (nt == 3) return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
+        if (nt == 4) return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16
+        if (nt == 6) return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
     }
-    return pat ? launch_sweep<MODE, G, true, 0>(a, s) : launch_sweep<MODE, G, false, 0>(a, s);
+    return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
 }
 
 template <int MODE>
@@ -1112,8 +1171,13 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         if (p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
         if (p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
     }
+    if (p->trace == MCQ_TRACE_REDUCED && (!out->step_sum || !out->step_sumsq || !out->step_accepted || !out->step_count))
+        return fail(MCQ_EINVAL, "reduced trace requested without step_sum / step_sumsq / step_accepted / step_count");
     hipStream_t s = (hipStream_t)hip_stream;
     if (p->n_chains == 0) {
+        if (p->trace == MCQ_TRACE_REDUCED)
+            for (int64_t* arr : {out->step_sum, out->step_sumsq, out->step_accepted, out->step_count})
+                HIP_TRY(hipMemsetAsync(arr, 0, (size_t)(p->n_steps + 1) * 8, s));
         if (ev)
             for (int t = 0; t < 3; t++) HIP_TRY(hipEventRecord(ev[t], s));
         return MCQ_OK;
@@ -1125,6 +1189,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (a.out.accept_bits)  // chains that stop early leave their later words untouched
         HIP_TRY(hipMemsetAsync(a.out.accept_bits, 0, (size_t)p->n_chains * p->bits_stride * 8, s));
 
+    if (a.red) HIP_TRY(hipMemsetAsync(a.red, 0, red_bytes(p), s));
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     if (p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM) init_lds += (size_t)p->N * p->N * p->N * 2;
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
@@ -1137,6 +1202,12 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     const int G = p->lanes_per_chain ? p->lanes_per_chain : mcq_default_lanes(p->mode);
     rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
+    if (a.red) {
+        const long long n_entries = p->n_steps + 1;
+        hipLaunchKernelGGL(mcq_reduced_finalize_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s, a.red, a.red_len, n_entries,
+                           (long long*)out->step_sum, (long long*)out->step_sumsq, (long long*)out->step_accepted, (long long*)out->step_count);
+        HIP_TRY(hipGetLastError());
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     return MCQ_OK;
 }
@@ -1164,7 +1235,7 @@ size_t mcq_state_bytes(int32_t N, int32_t mode) {
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
-    return beta_tab_bytes(p) + c32_tab_bytes(p) + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -1267,6 +1338,10 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
         {(void**)&d.near_ties, out->near_ties, n * 8},
         {(void**)&d.best_state, out->best_state, n * sb},
         {(void**)&d.final_state, out->final_state, n * sb},
+        {(void**)&d.step_sum, p->trace == MCQ_TRACE_REDUCED ? out->step_sum : nullptr, (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_sumsq, p->trace == MCQ_TRACE_REDUCED ? out->step_sumsq : nullptr, (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_accepted, p->trace == MCQ_TRACE_REDUCED ? out->step_accepted : nullptr, (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_count, p->trace == MCQ_TRACE_REDUCED ? out->step_count : nullptr, (size_t)(p->n_steps + 1) * 8},
     };
     uint32_t* d_seeds = nullptr;
     void* d_ws = nullptr;

@@ -55,7 +55,7 @@ def run(params, seeds, trace=True, states=True, n_threads=1):
     for k, a in arrays.items():
         setattr(out, k, a.ctypes.data)
     p = abi.Params.from_buffer_copy(params)
-    p.trace = abi.TRACE_I32 if trace else abi.TRACE_NONE
+    p.trace = abi.trace_mode(trace)
     rc = lib().mcq_oracle_run(C.byref(p), seeds.ctypes.data, C.byref(out), int(n_threads))
     if rc != 0:
         msg = lib().mcq_oracle_last_error().decode()

@@ -176,3 +176,31 @@ def test_on_device_trace_statistics():
             m2, s2 = dr.mean_std_from_sums(st["step_sum"], st["step_sumsq"], st["step_count"])
             np.testing.assert_array_equal(m2, mean)
             np.testing.assert_allclose(s2, std, rtol=1e-12)
+
+
+def test_reduced_trace_equals_statistics_of_the_full_trace():
+    """trace == REDUCED (per-entry sums accumulated inside the sweep) against mcq_trace_stats_device on a full-trace
+    run of the same chains, with and without early stops, for every lane width, ragged chain counts included."""
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    for mode, N, patience, n_steps, n_chains in (("board", 8, None, 1000, 77), ("board", 8, 60, 1500, 77), ("board", 12, None, 333, 16),
+                                                   ("full_3d", 6, None, 700, 41)):
+        for lanes in LANES:
+            p = abi.make_params(N, n_steps, "random", sp, n_chains, mcmc_type=mode, early_stop_patience=patience, lanes_per_chain=lanes)
+            seeds = abi.seeds_for(11, n_chains)
+            full = mcq_amd._lib.DeviceRun(p, seeds)
+            full.launch()
+            st = full.trace_stats(n_bins=10)
+            res = full.results()
+            red, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced", states=False)
+            what = f"{mode} N={N} patience={patience} G={lanes}"
+            np.testing.assert_array_equal(red["step_sum"], st["step_sum"], err_msg=what)
+            np.testing.assert_array_equal(red["step_sumsq"], st["step_sumsq"], err_msg=what)
+            np.testing.assert_array_equal(red["step_count"], st["step_count"], err_msg=what)
+            acc = np.zeros(n_steps + 1, dtype=np.int64)  # accepted[e] = chains whose step e - 1 was accepted
+            for r in range(n_chains):
+                a_steps, _ = mcq_amd.experiments.accepted_rejected_steps(res, r)
+                a_steps = a_steps[a_steps + 1 < res["hist_len"][r]]  # the early-stop step is executed but has no history entry
+                acc[a_steps + 1] += 1
+            np.testing.assert_array_equal(red["step_accepted"], acc, err_msg=what)
+            for k in ("best_energy", "final_energy", "steps_to_best", "n_accepted", "hist_len"):
+                np.testing.assert_array_equal(red[k], res[k], err_msg=f"{what}: {k}")
