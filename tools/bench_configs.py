@@ -37,7 +37,13 @@ def run_set(name, jobs, trace):
     moves = sum(int(r.t["steps_executed"].sum().item()) for r in runs)
     best = [int(r.t["best_energy"].min().item()) for r in runs]
     line = {"config": name, "launches": len(runs), "chains": sum(j["n_chains"] for j in jobs), "moves": moves, "seconds": dt,
-            "moves_per_s": moves / dt, "min_energy_per_launch": best, "trace": "i32" if trace else "none"}
+            "moves_per_s": moves / dt, "min_energy_per_launch": best, "trace": trace if isinstance(trace, str) else ("i32" if trace else "none")}
+    if trace == "reduced":  # the statistics the reference plots, straight from the accumulators
+        t = runs[0].t
+        n = t["step_count"].double()
+        mean = t["step_sum"].double() / n
+        line["mean_energy_at"] = {str(e): float(mean[e]) for e in (0, len(mean) // 4, len(mean) // 2, len(mean) - 1)}
+        line["accepted_total"] = int(t["step_accepted"].sum().item())
     print(json.dumps(line), flush=True)
     del runs
     torch.cuda.empty_cache()
@@ -50,6 +56,10 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     n = a.n_steps
+    if a.only in ("c2r",):
+        run_set("C2 single_N N=12 board linear 1->3, 65536 chains, 10^6 steps, trace=reduced",
+                [dict(N=12, n_steps=1000000, init="random", sp={"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0},
+                      n_chains=65536, mode="board", seed=42)], trace="reduced")
     if a.only in ("", "c3"):
         run_set("C3 single_N N=12 full_3d exponential 1->3, 65536 chains",
                 [dict(N=12, n_steps=n, init="random", sp={"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0},
