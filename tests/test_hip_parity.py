@@ -53,6 +53,10 @@ CASES = [
     (16, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 800, 20, None),
     (21, "board", "random", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 600, 9, None),
     (25, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 400, 7, None),
+    # largest supported boards: 64 KB permutation array in the init kernel, 5-bit coordinate packing, bit 31 of the masks
+    (32, "full_3d", "random", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 2.0}, 150, 3, None),
+    (31, "board", "klarner", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 300, 5, 80),
+    (32, "full_3d", "klarner", {"type": "constant", "beta_const": 1.0}, 120, 2, None),
 ]
 
 
