@@ -208,3 +208,16 @@ def test_reduced_trace_equals_statistics_of_the_full_trace():
             np.testing.assert_array_equal(red["step_accepted"], acc, err_msg=what)
             for k in ("best_energy", "final_energy", "steps_to_best", "n_accepted", "hist_len"):
                 np.testing.assert_array_equal(red[k], res[k], err_msg=f"{what}: {k}")
+
+
+def test_long_runs_full_trace():
+    """Tens of thousands of steps: ~300 MT19937 generations per chain, thousands of ring wrap-arounds and history
+    blocks, the whole annealing range of beta -- full traces against the oracle, both modes."""
+    for mode, sp, n_steps, n_chains in (("board", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 60000, 192),
+                                        ("full_3d", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 25000, 96)):
+        p = abi.make_params(12, n_steps, "random", sp, n_chains, mcmc_type=mode)
+        seeds = abi.seeds_for(4242, n_chains)
+        want = oracle.run(p, seeds, n_threads=16)
+        got, _ = mcq_amd._lib.run_host(p, seeds)
+        util.assert_results_equal(got, want, f"long run {mode}")
+        assert got["near_ties"].sum() == 0
