@@ -76,6 +76,7 @@ namespace {
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 constexpr int RING = 64;          // ready (tempered) words per chain
+constexpr int RING_MIRROR = 32;   // slots 0..31 are repeated behind the ring: a proposal reads up to 31 slots past pos without wrapping
 constexpr int RED_STRIPES = 8;    // trace == REDUCED: independent accumulator copies, so one address sees few atomics
 constexpr int REC_POS = 624;      // record word: MT index of the next word to consume
 constexpr int REC_GEN_END = 625;  // record word: words [0, gen_end) belong to the current generation
@@ -456,6 +457,7 @@ struct Stream {
             v[w] = px[w] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
             const uint32_t t = temper(v[w]);
             ring[so + gl * WPL + w] = t;
+            ring[(so < RING_MIRROR ? so + RING : so) + gl * WPL + w] = t;  // mirror of slots 0..31 (otherwise the same store again)
             bits |= ((t & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
             if (HASQ) bitsq |= ((t & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
         }
@@ -487,6 +489,7 @@ struct Stream {
                 if (t >= rpos && t < rge) {
                     const uint32_t x = temper(*word(t));
                     ring[t & (RING - 1)] = x;
+                    if ((t & (RING - 1)) < RING_MIRROR) ring[(t & (RING - 1)) + RING] = x;
                     bits |= ((x & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
                     bitsq |= ((x & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
                 }
@@ -512,9 +515,10 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
     return 1;
 }
 
-// LDS per chain: ring[64] | stage[16] | board: pad[8], heights bytes, pad[8] | full_3d: pad[32], column words [Q], pad[32], queens uint16 [Q]
-constexpr int LDS_STAGE = RING;            // word offset of the energy_history staging block
-constexpr int LDS_STATE = RING + 16;       // word offset of the state
+// LDS per chain: ring[64 + 32 mirrored] | stage[16] | board: pad, heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
+//                full_3d: pad[32], column words [Q], pad[32], queens uint16 [Q]
+constexpr int LDS_STAGE = RING + RING_MIRROR;  // word offset of the energy_history staging block
+constexpr int LDS_STATE = LDS_STAGE + 16;     // word offset of the state
 constexpr int FULL_PAD = 32;               // full_3d: spare words on either side of the column words (N <= 32)
 
 // trace == REDUCED: add the block of 16 history entries [e0, e0 + 16) of the wavefront's chains to the per-entry
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     uint32_t* base = lds + grp * a.chain_lds_words;
     uint32_t* ring = base;
     uint32_t* stage = base + LDS_STAGE;
-    uint8_t* hts = (uint8_t*)(base + LDS_STATE + 8);  // board (the diagonal probes read up to N-1 bytes outside either end)
+    uint8_t* hts = (uint8_t*)(base + LDS_STATE + (N + 2) / 4);  // board (the diagonal probes read up to N-1 bytes outside either end)
     // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
     // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
     uint32_t* colw = base + LDS_STATE + FULL_PAD;
@@ -727,13 +731,15 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const uint32_t top = 0x80000000u;  // keeps ctz defined when a mask is empty (view_ok is false then)
                 const uint32_t p1 = __builtin_ctz(v1 | top), p2 = __builtin_ctz(v2 | top), p3 = __builtin_ctz(v3 | top);
                 const uint32_t p4 = __builtin_ctz(v4 | top), p5 = __builtin_ctz(v5 | top);
-                const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)];
-                const uint32_t w3 = ring[(s + p3) & (RING - 1)], w4 = ring[(s + p4) & (RING - 1)], w5 = ring[(s + p5) & (RING - 1)];
-                // the uniform's two words follow whichever candidate becomes new_k: all three pairs are requested now, so
-                // that nothing has to wait for the old height (one LDS round trip less on the step's critical path)
-                const uint32_t u31 = ring[(s + p3 + 1) & (RING - 1)], u32 = ring[(s + p3 + 2) & (RING - 1)];
-                const uint32_t u41 = ring[(s + p4 + 1) & (RING - 1)], u42 = ring[(s + p4 + 2) & (RING - 1)];
-                const uint32_t u51 = ring[(s + p5 + 1) & (RING - 1)], u52 = ring[(s + p5 + 2) & (RING - 1)];
+                // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  Each candidate for new_k is
+                // fetched together with the two words that follow it -- the uniform's words if it becomes new_k -- off one
+                // base address, so nothing has to wait for the old height (one LDS round trip less on the critical path).
+                const uint32_t* rs = ring + s;
+                const uint32_t w1 = rs[p1], w2 = rs[p2];
+                const uint32_t *r3 = rs + p3, *r4 = rs + p4, *r5 = rs + p5;
+                const uint32_t w3 = r3[0], u31 = r3[1], u32 = r3[2];
+                const uint32_t w4 = r4[0], u41 = r4[1], u42 = r4[2];
+                const uint32_t w5 = r5[0], u51 = r5[1], u52 = r5[2];
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
                 const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN), c5 = (int)(w5 & maskN);
                 cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
@@ -1107,9 +1113,9 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     }
     a->state_bytes = (int)mcq_state_bytes(p->N, p->mode);
     a->rec_words = rec_words_for(p);
-    // board: the diagonal probes read up to N-1 bytes before / after the heights; 8 spare words on each
+    // board: the diagonal probes read up to N-1 bytes before / after the heights; (N+2)/4 spare words on each
     // side keep those (discarded) reads inside the chain's own LDS slice.
-    a->chain_lds_words = LDS_STATE + (p->mode == MCQ_MODE_BOARD ? 8 + (a->Q + 3) / 4 + 8 : FULL_PAD + a->Q + FULL_PAD + (a->Q + 1) / 2);
+    a->chain_lds_words = LDS_STATE + (p->mode == MCQ_MODE_BOARD ? 2 * ((p->N + 2) / 4) + (a->Q + 3) / 4 : FULL_PAD + a->Q + FULL_PAD + (a->Q + 1) / 2);
     a->chain_lds_words = (a->chain_lds_words + 3) & ~3;  // 16-byte multiple: the staging block is read with ds_read_b128
     a->beta_const = p->beta_const, a->beta_start = p->beta_start, a->beta_end = p->beta_end;
     a->n_steps = p->n_steps, a->n_chains = p->n_chains;
