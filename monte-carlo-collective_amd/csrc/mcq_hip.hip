@@ -903,13 +903,17 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 qn[qi] = (uint16_t)newp;
             }
             E += acc ? dE : 0;
-            n_acc += acc ? 1 : 0;
-            const bool improved = acc && E < best;
-            best = improved ? E : best;
+            const bool improved = E < best;  // only an accepted move can get below the best so far (E >= best otherwise)
+            best = min(best, E);
             if (PATIENCE) no_imp = improved ? 0 : no_imp + 1;
-            if (__any(improved) && a.out.best_state) {  // rare after the first few hundred steps
+            const int e = step + 1;
+            if (__any(improved)) {  // rare after the first few hundred steps
                 if (improved) {
-                    uint8_t* bo = a.out.best_state + chain * (long long)a.state_bytes;
+                    // first index of the minimum of energy_history (experiments.py:364-365); with patience 0 the chain stops
+                    // right here without appending this entry (no_imp = 0 >= 0), so the index stays
+                    if (!PATIENCE || patience > 0) best_step = e;
+                    uint8_t* bo = a.out.best_state ? a.out.best_state + chain * (long long)a.state_bytes : nullptr;
+                    if (bo) {
                     if (MODE == MCQ_MODE_BOARD) {
                         for (int c = gl; c < Q; c += G) bo[c] = hts[c];
                     } else {
@@ -918,10 +922,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                             bo[3 * c] = (uint8_t)(pq & 31), bo[3 * c + 1] = (uint8_t)((pq >> 5) & 31), bo[3 * c + 2] = (uint8_t)((pq >> 10) & 31);
                         }
                     }
+                    }
                 }
             }
 
-            const int e = step + 1;
             if (PATIENCE && no_imp >= patience) {
                 // break BEFORE the append (experiments.py:349-353): entries 0..step are valid
                 active = false;
@@ -929,16 +933,17 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 if (trace)
                     for (int w = 0; w < WPL; w++)
                         if (gl * WPL + w <= (step & 15)) hist[(step & ~15) + w] = (int)stage[gl * WPL + w];
+                n_acc += __popc(accw);
                 if (bits && gl == 0) bits[step >> 5] = accw;
             } else {
                 stage[e & 15] = (uint32_t)E | (reduced && acc ? 0x80000000u : 0u);  // bit 31: this entry's step was accepted
-                best_step = improved ? e : best_step;
                 if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
                     if constexpr (WPL == 4) *(uint4*)(hist + e - 15) = *(const uint4*)(stage + gl * 4);
                     else if constexpr (WPL == 2) *(uint2*)(hist + e - 15) = *(const uint2*)(stage + gl * 2);
                     else hist[e - 15] = (int)stage[gl];
                 }
                 if ((step & 31) == 31) {
+                    n_acc += __popc(accw);  // accepted moves are counted from the bit words
                     if (bits && gl == 0) bits[step >> 5] = accw;
                     accw = 0;
                 }
@@ -958,6 +963,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         if (trace && (n_steps & 15) != 15)
             for (int w = 0; w < WPL; w++)
                 if (gl * WPL + w <= (n_steps & 15)) hist[(n_steps & ~15) + w] = (int)stage[gl * WPL + w];
+        if ((n_steps & 31) != 0) n_acc += __popc(accw);
         if (bits && gl == 0 && (n_steps & 31) != 0) bits[n_steps >> 5] = accw;
     }
     if (chain < a.n_chains) {
