@@ -354,6 +354,19 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
 // ------------------------------------------------------------------------------------------------
 // sweep kernel
 // ------------------------------------------------------------------------------------------------
+// wave-uniform "some lane has p": the ballot is compared in the scalar unit (no per-lane 0/1 materialised)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// Attack masks of an (old, new) height pair in one register, N <= 16: low half B_old, high half B_new, each half
+// becomes B | B << d | B >> d within its 16 bits (packed 16-bit shifts; bits >= 16 of a half are never probed).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_star(uint32_t bb, uint32_t d) {
+    const u16x2 v = __builtin_bit_cast(u16x2, bb);
+    const u16x2 dd = {(unsigned short)d, (unsigned short)d};
+    const u16x2 l = v << dd, r = v >> dd;
+    return bb | __builtin_bit_cast(uint32_t, l) | __builtin_bit_cast(uint32_t, r);
+}
+
 // DPP reductions over the G lanes of a group (G = 4, 8 or 16), result in every lane of the group.
 template <int G>
 __device__ __forceinline__ int group_sum(int v) {
@@ -437,10 +450,19 @@ struct Stream {
         }
         const int in = i0 + WPL;
         pn = *word(in == MT_N ? 0 : in);  // word 623 pairs with the NEW word 0, already written back
+        if constexpr (WPL == 4) {
+            // i0 is a multiple of 4, so (i0 + 397) mod 624 is 1 mod 4: the lane's four words are contiguous except that
+            // the last one wraps to word 0 when they start at 621
+            const int ix0 = i0 + MT_M >= MT_N ? i0 + MT_M - MT_N : i0 + MT_M;
+            const uint32_t* x = word(ix0);
+            px[0] = x[0], px[1] = x[1], px[2] = x[2];
+            px[3] = *word(ix0 == MT_N - 3 ? 0 : ix0 + 3);
+        } else {
 #pragma unroll
-        for (int w = 0; w < WPL; w++) {
-            const int ix = i0 + w + MT_M;
-            px[w] = *word(ix >= MT_N ? ix - MT_N : ix);
+            for (int w = 0; w < WPL; w++) {
+                const int ix = i0 + w + MT_M;
+                px[w] = *word(ix >= MT_N ? ix - MT_N : ix);
+            }
         }
         pending = true;
     }
@@ -640,6 +662,26 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)a.c32_tab;
     const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)a.beta_tab;
 
+    // Packed dE probes (board, N = 9..16 <=> NT = 3 or 4): lane constants of the NT columns / rows this lane probes.
+    //   pm      probe index m = gl + t*G, clamped into the board (a clamped probe has all-zero selectors below)
+    //   krc     selector of the row / column probe: one bit per half
+    //   vdm     bit (j - i + 16) set iff the diagonal probe (m, m - i + j) is on the board
+    //   vam     bit (i + j) set iff the anti-diagonal probe (m, i + j - m) is
+    constexpr bool PACKED = MODE == MCQ_MODE_BOARD && (NT == 3 || NT == 4);
+    constexpr int NTP = PACKED ? NT : 1;
+    int pm[NTP];
+    uint32_t krc[NTP], vdm[NTP], vam[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; t++) {
+        const int m = gl + t * G;
+        const bool inb = m < N;
+        const uint32_t full = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
+        pm[t] = inb ? m : N - 1;
+        krc[t] = inb ? 0x00010001u : 0u;
+        vdm[t] = inb && PACKED ? full << ((16 - pm[t]) & 31) : 0u;
+        vam[t] = inb && PACKED ? full << (pm[t] & 31) : 0u;
+    }
+
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
     int last_entry = n_steps;  // wave-uniform: the last history entry any chain of the wavefront can have reached
@@ -780,7 +822,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 batched = view_ok && (free1 || free2);
                 rng.pos += batched ? (free1 ? p3 : p6) + 3 : 0u;
             }
-            if (__any(!batched)) {  // wave-uniform guard of the rare path
+            if (wave_any(!batched)) {  // wave-uniform guard of the rare path
                 if (!batched) sequential();
             }
 
@@ -818,14 +860,36 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     acc += in_board && (unsigned)(m + dji) < (unsigned)N ? cd : 0;
                     acc += in_board && (unsigned)(sij - m) < (unsigned)N ? ca : 0;
                 };
-                if constexpr (NT > 0) {
+                if constexpr (PACKED) {
+                    // both heights ride in one register (pk_star); a probe shifts the pair of masks right by the probed
+                    // height, which leaves "attacks old_k" in bit 0 and "attacks new_k" in bit 16, and the selected bits
+                    // are summed as two 16-bit counters.  No select depends on a loaded value and none guards a load, so
+                    // all 4*NT byte reads are in flight together.
+                    const uint32_t BB = Bo | (Bn << 16);
+                    const uint32_t shd = (uint32_t)(dji + 16), sha = (uint32_t)sij;
+                    uint32_t accp = 0;
 #pragma unroll
-                    for (int t = 0; t < NT; t++) probe(gl + t * G, t + 1 < NT || gl + t * G < N);
+                    for (int t = 0; t < NT; t++) {
+                        const int m = pm[t], mN_ = __mul24(m, N);
+                        const uint32_t hr = hrow[m], hc = hj[mN_], hdg = hd[mN_ + m], han = ha[mN_ - m];
+                        const uint32_t Mr = pk_star(BB, abs_diff(m, j)), Mc = pk_star(BB, abs_diff(m, i));
+                        const uint32_t vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1) & 0x00010001u;
+                        const uint32_t va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1) & 0x00010001u;
+                        accp += ((Mr >> (hr & 31u)) & krc[t]) + ((Mc >> (hc & 31u)) & krc[t]);
+                        accp += ((Mc >> (hdg & 31u)) & vd) + ((Mc >> (han & 31u)) & va);
+                    }
+                    const uint32_t both = (uint32_t)group_sum<G>((int)accp);  // at most 4 * N hits per half: no carry
+                    dE = (int)(both >> 16) - (int)(both & 0xffffu) + 4;
                 } else {
+                    if constexpr (NT > 0) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++) probe(gl + t * G, t + 1 < NT || gl + t * G < N);
+                    } else {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                    for (int m = gl; m < N; m += G) probe(m, true);
+                        for (int m = gl; m < N; m += G) probe(m, true);
+                    }
+                    dE = group_sum<G>(acc) + 4;
                 }
-                dE = group_sum<G>(acc) + 4;
             } else {
                 // conflicts_for_queen(q, new) - conflicts_for_queen(q) (mcmc.py:185-226) without visiting the queens:
                 // the 13 lines through a cell (ci,cj,ck) are the column itself plus, for every column (i2,j2) on the
@@ -883,7 +947,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 acc = acc || sure_acc;
                 exact = xneg && !sure_acc && !sure_rej;
             }
-            if (__any(exact)) {  // ~0.1 % of the steps of a chain
+            if (wave_any(exact)) {  // ~0.1 % of the steps of a chain
                 if (exact) {
                     const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
                     acc = (r & 1) != 0, ties += r >> 1;
@@ -907,7 +971,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             best = min(best, E);
             if (PATIENCE) no_imp = improved ? 0 : no_imp + 1;
             const int e = step + 1;
-            if (__any(improved)) {  // rare after the first few hundred steps
+            if (wave_any(improved)) {  // rare after the first few hundred steps
                 if (improved) {
                     // first index of the minimum of energy_history (experiments.py:364-365); with patience 0 the chain stops
                     // right here without appending this entry (no_imp = 0 >= 0), so the index stays
@@ -951,7 +1015,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         }
         STAMP(5);  // apply + history
         if (reduced && ((step + 1) & 15) == 15) reduce_block<G>(stage, gl, grp, (step + 1) & ~15, hist_len, red, a.red_len);
-        if (PATIENCE && !__any(active)) {
+        if (PATIENCE && !wave_any(active)) {
             last_entry = step + 1;
             break;
         }
