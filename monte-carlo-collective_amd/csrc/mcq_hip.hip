@@ -78,9 +78,10 @@ constexpr int MT_M = 397;
 constexpr int RING = 64;          // ready (tempered) words per chain
 constexpr int RING_MIRROR = 32;   // slots 0..31 are repeated behind the ring: a proposal reads up to 31 slots past pos without wrapping
 constexpr int RED_STRIPES = 8;    // trace == REDUCED: independent accumulator copies, so one address sees few atomics
-constexpr int REC_POS = 624;      // record word: MT index of the next word to consume
-constexpr int REC_GEN_END = 625;  // record word: words [0, gen_end) belong to the current generation
-constexpr int REC_E0 = 626;       // record word: initial energy
+constexpr int REC_MIRROR = 624;   // record word: copy of MT word 0, so that words i+1 and i+397.. of a block never wrap inside a lane's run
+constexpr int REC_POS = 625;      // record word: MT index of the next word to consume
+constexpr int REC_GEN_END = 626;  // record word: words [0, gen_end) belong to the current generation
+constexpr int REC_E0 = 627;       // record word: initial energy
 constexpr int REC_STATE = 628;    // first word of the state bytes (heights or (i,j,k) triplets)
 
 struct KArgs {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
 
     uint32_t* rec = a.ws + chain * (long long)a.rec_words;
     for (int w = lane; w < MT_N; w += 64) rec[w] = mt[w];
-    if (lane == 0) rec[REC_POS] = (uint32_t)rng.pos, rec[REC_GEN_END] = (uint32_t)rng.gen_end, rec[REC_E0] = (uint32_t)e;
+    if (lane == 0) rec[REC_MIRROR] = mt[0], rec[REC_POS] = (uint32_t)rng.pos, rec[REC_GEN_END] = (uint32_t)rng.gen_end, rec[REC_E0] = (uint32_t)e;
     uint8_t* rst = (uint8_t*)(rec + REC_STATE);
     for (int c = lane; c < a.state_bytes; c += 64) rst[c] = st[c];
 }
@@ -436,34 +437,29 @@ struct Stream {
     // MT word `idx` of this chain: uniform base + 32-bit offset, so the address needs no 64-bit vector math
     __device__ __forceinline__ uint32_t* word(int idx) const { return (uint32_t*)(wbase + (coff + 4u * (uint32_t)idx)); }
 
-    // load the inputs of block gi: words i, i+1 and (i+397) mod 624 for the lane's WPL words
+    // load the inputs of block gi: words i, i+1 and (i+397) mod 624 for the lane's WPL words.  Word 624 of the record
+    // mirrors word 0 (the NEW word 0, regenerated earlier in the same pass), which is what index 624 stands for in both
+    // roles; the lane's run of (i+397) mod 624 starts at 1 mod 4, so it can only run over the end by that one word.
     __device__ __forceinline__ void issue() {
+        struct __attribute__((packed, aligned(4))) W4 { uint32_t x, y, z, w; };
+        struct __attribute__((packed, aligned(4))) W2 { uint32_t x, y; };
         const int i0 = gi + gl * WPL;
+        const int ix0 = i0 + MT_M >= MT_N ? i0 + MT_M - MT_N : i0 + MT_M;
         if constexpr (WPL == 4) {
             const uint4 q = *(const uint4*)word(i0);
             pa[0] = q.x, pa[1] = q.y, pa[2] = q.z, pa[3] = q.w;
+            const W4 x = *(const W4*)word(ix0);
+            px[0] = x.x, px[1] = x.y, px[2] = x.z, px[3] = x.w;
         } else if constexpr (WPL == 2) {
             const uint2 q = *(const uint2*)word(i0);
             pa[0] = q.x, pa[1] = q.y;
+            const W2 x = *(const W2*)word(ix0);
+            px[0] = x.x, px[1] = x.y;
         } else {
             pa[0] = *word(i0);
+            px[0] = *word(ix0);
         }
-        const int in = i0 + WPL;
-        pn = *word(in == MT_N ? 0 : in);  // word 623 pairs with the NEW word 0, already written back
-        if constexpr (WPL == 4) {
-            // i0 is a multiple of 4, so (i0 + 397) mod 624 is 1 mod 4: the lane's four words are contiguous except that
-            // the last one wraps to word 0 when they start at 621
-            const int ix0 = i0 + MT_M >= MT_N ? i0 + MT_M - MT_N : i0 + MT_M;
-            const uint32_t* x = word(ix0);
-            px[0] = x[0], px[1] = x[1], px[2] = x[2];
-            px[3] = *word(ix0 == MT_N - 3 ? 0 : ix0 + 3);
-        } else {
-#pragma unroll
-            for (int w = 0; w < WPL; w++) {
-                const int ix = i0 + w + MT_M;
-                px[w] = *word(ix >= MT_N ? ix - MT_N : ix);
-            }
-        }
+        pn = *word(i0 + WPL);
         pending = true;
     }
 
@@ -486,6 +482,7 @@ struct Stream {
         if constexpr (WPL == 4) *(uint4*)word(i0) = make_uint4(v[0], v[1], v[2], v[3]);
         else if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
         else *word(i0) = v[0];
+        if (i0 == 0) *word(REC_MIRROR) = v[0];
         set_field(ok_lo, ok_hi, so, group_or<G>(bits));
         if (HASQ) set_field(okq_lo, okq_hi, so, group_or<G>(bitsq));
         gen += 16;
