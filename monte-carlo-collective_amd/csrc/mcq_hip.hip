@@ -413,13 +413,22 @@ struct Stream {
     int gl;
     unsigned maskN, mN, maskQ, mQ;
     uint32_t tc1, tc2;  // tempering masks, kept in scalar registers so that (y << s) & c ^ y is one 3-input op
+    uint32_t tlow, tmat;   // 0x7fffffff and the twist matrix 0x9908b0df, scalar registers as well
+    uint32_t okM4, okK4;   // maskN and 0x80 + (N - 1) in each byte: four randint(0, N) accept tests in one subtraction
 
     __device__ __forceinline__ uint32_t temper(uint32_t y) const {
         y ^= y >> 11;
-        y ^= (y << 7) & tc1;
-        y ^= (y << 15) & tc2;
+        y = __builtin_amdgcn_bitop3_b32(y << 7, tc1, y, 0x6a);   // ((y << 7) & c1) ^ y
+        y = __builtin_amdgcn_bitop3_b32(y << 15, tc2, y, 0x6a);  // ((y << 15) & c2) ^ y
         y ^= y >> 18;
         return y;
+    }
+    // new raw word from words i (top bit), i+1 (low 31 bits) and i+397
+    __device__ __forceinline__ uint32_t twist(uint32_t cur, uint32_t nxt, uint32_t x) const {
+        uint32_t y;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(tlow), "v"(nxt), "v"(cur));  // (nxt & 0x7fffffff) | (cur & 0x80000000)
+        const uint32_t odd = (uint32_t)__builtin_amdgcn_sbfe((int)nxt, 0, 1);       // all ones iff y is odd
+        return __builtin_amdgcn_bitop3_b32(odd, tmat, y >> 1, 0x6a) ^ x;           // ((odd & matrix) ^ (y >> 1)) ^ x
     }
 
     static __device__ __forceinline__ void set_field(uint32_t& lo, uint32_t& hi, int so, uint32_t bits16) {
@@ -467,21 +476,36 @@ struct Stream {
     __device__ __forceinline__ void complete() {
         const int i0 = gi + gl * WPL;
         const int so = gen & (RING - 1);
-        uint32_t v[WPL], bits = 0, bitsq = 0;
+        uint32_t v[WPL], t[WPL], bits = 0, bitsq = 0;
 #pragma unroll
         for (int w = 0; w < WPL; w++) {
-            const uint32_t nxt = w + 1 < WPL ? pa[(w + 1) % WPL] : pn;
-            const uint32_t y = (pa[w] & 0x80000000u) | (nxt & 0x7fffffffu);
-            v[w] = px[w] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            const uint32_t t = temper(v[w]);
-            ring[so + gl * WPL + w] = t;
-            ring[(so < RING_MIRROR ? so + RING : so) + gl * WPL + w] = t;  // mirror of slots 0..31 (otherwise the same store again)
-            bits |= ((t & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
-            if (HASQ) bitsq |= ((t & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
+            v[w] = twist(pa[w], w + 1 < WPL ? pa[(w + 1) % WPL] : pn, px[w]);
+            t[w] = temper(v[w]);
         }
-        if constexpr (WPL == 4) *(uint4*)word(i0) = make_uint4(v[0], v[1], v[2], v[3]);
-        else if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
-        else *word(i0) = v[0];
+        uint32_t* slot = ring + so + gl * WPL;
+        uint32_t* mirror = ring + (so < RING_MIRROR ? so + RING : so) + gl * WPL;  // mirror of slots 0..31 (otherwise the same store again)
+        if constexpr (WPL == 4) {
+            *(uint4*)word(i0) = make_uint4(v[0], v[1], v[2], v[3]);
+            *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
+            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
+            // the low bytes of the four words side by side; per byte (0x80 + N - 1) - (t & maskN) keeps bit 7 iff the
+            // word passes; a dot product with (1, 2, 4, 8) collects the four flags
+            const uint32_t b01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x04000c0cu);
+            const uint32_t d = okK4 - ((b01 | b23) & okM4);
+            bits = __builtin_amdgcn_udot4((d >> 7) & 0x01010101u, 0x08040201u, 0u, false) << (gl * 4);
+        } else {
+            if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
+            else *word(i0) = v[0];
+#pragma unroll
+            for (int w = 0; w < WPL; w++) {
+                slot[w] = t[w], mirror[w] = t[w];
+                bits |= ((t[w] & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
+            }
+        }
+        if (HASQ) {
+#pragma unroll
+            for (int w = 0; w < WPL; w++) bitsq |= ((t[w] & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
+        }
         if (i0 == 0) *word(REC_MIRROR) = v[0];
         set_field(ok_lo, ok_hi, so, group_or<G>(bits));
         if (HASQ) set_field(okq_lo, okq_hi, so, group_or<G>(bitsq));
@@ -495,6 +519,9 @@ struct Stream {
     __device__ __forceinline__ void attach(char* wave_base, uint32_t chain_off, uint32_t* lds_ring, int rpos, int rge, int gl_, unsigned maskN_,
                                            unsigned mN_, unsigned maskQ_, unsigned mQ_, uint32_t c1, uint32_t c2) {
         wbase = wave_base, coff = chain_off, ring = lds_ring, gl = gl_, maskN = maskN_, mN = mN_, maskQ = maskQ_, mQ = mQ_, tc1 = c1, tc2 = c2;
+        tlow = 0x7fffffffu, tmat = 0x9908b0dfu;
+        asm volatile("" : "+s"(tlow), "+s"(tmat));  // opaque scalars, like tc1 / tc2
+        okM4 = maskN_ * 0x01010101u, okK4 = (0x80u + mN_) * 0x01010101u;  // maskN, N - 1 <= 31
         okq_lo = okq_hi = 0;
         pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge;
         ok_lo = ok_hi = 0, pending = false, pn = 0;
@@ -534,10 +561,12 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
     return 1;
 }
 
-// LDS per chain: ring[64 + 32 mirrored] | stage[16] | board: pad, heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
+// LDS per chain: stage[16] | ring[64 + 32 mirrored] | board: pad, heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
 //                full_3d: pad[32], column words [Q], pad[32], queens uint16 [Q]
-constexpr int LDS_STAGE = RING + RING_MIRROR;  // word offset of the energy_history staging block
-constexpr int LDS_STATE = LDS_STAGE + 16;     // word offset of the state
+// (the staging block sits in front of the ring so that ring[-1], which an unused draw position may address, is the chain's own)
+constexpr int LDS_STAGE = 0;                          // word offset of the energy_history staging block
+constexpr int LDS_RING = 16;                          // word offset of the ring
+constexpr int LDS_STATE = LDS_RING + RING + RING_MIRROR;  // word offset of the state
 constexpr int FULL_PAD = 32;               // full_3d: spare words on either side of the column words (N <= 32)
 
 // trace == REDUCED: add the block of 16 history entries [e0, e0 + 16) of the wavefront's chains to the per-entry
@@ -601,7 +630,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     const long long crow = active ? chain : 0;
 
     uint32_t* base = lds + grp * a.chain_lds_words;
-    uint32_t* ring = base;
+    uint32_t* ring = base + LDS_RING;
     uint32_t* stage = base + LDS_STAGE;
     uint8_t* hts = (uint8_t*)(base + LDS_STATE + (N + 2) / 4);  // board (the diagonal probes read up to N-1 bytes outside either end)
     // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
@@ -767,9 +796,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
                 // a fifth accepted word with the two words of the uniform still inside the view, and a full view
                 const bool view_ok = (v5 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
-                const uint32_t top = 0x80000000u;  // keeps ctz defined when a mask is empty (view_ok is false then)
-                const uint32_t p1 = __builtin_ctz(v1 | top), p2 = __builtin_ctz(v2 | top), p3 = __builtin_ctz(v3 | top);
-                const uint32_t p4 = __builtin_ctz(v4 | top), p5 = __builtin_ctz(v5 | top);
+                // an empty mask gives position -1 (view_ok is false then): the fetches below read ring[s - 1 ..], still the chain's own LDS
+                const int p1 = __ffs((int)v1) - 1, p2 = __ffs((int)v2) - 1, p3 = __ffs((int)v3) - 1, p4 = __ffs((int)v4) - 1, p5 = __ffs((int)v5) - 1;
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  Each candidate for new_k is
                 // fetched together with the two words that follow it -- the uniform's words if it becomes new_k -- off one
                 // base address, so nothing has to wait for the old height (one LDS round trip less on the critical path).
@@ -785,7 +813,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 old_k = hts[cell];
                 const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
                 pc = use3 ? c3 : use4 ? c4 : c5;
-                const uint32_t kp = use3 ? p3 : use4 ? p4 : p5;
+                const uint32_t kp = (uint32_t)(use3 ? p3 : use4 ? p4 : p5);
                 uw1 = use3 ? u31 : use4 ? u41 : u51, uw2 = use3 ? u32 : use4 ? u42 : u52;
                 batched = view_ok && pc != old_k;  // three candidates in a row equal to old_k (1/N^3): word by word instead
                 rng.pos += batched ? kp + 3 : 0u;
