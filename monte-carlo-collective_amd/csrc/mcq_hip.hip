@@ -784,6 +784,18 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             };
 
+            // packed dE probes: the probed heights depend on (i, j) only and are requested together with the old height
+            uint32_t ph[4 * NTP];
+            auto load_probes = [&]() {
+                const uint8_t* hrow = hts + __mul24(pa, N);
+                const uint8_t* hj = hts + pb;
+#pragma unroll
+                for (int t = 0; t < NTP; t++) {
+                    const int m = pm[t], mN_ = __mul24(m, N);
+                    ph[4 * t] = hrow[m], ph[4 * t + 1] = hj[mN_], ph[4 * t + 2] = hj[mN_ + m - pa], ph[4 * t + 3] = hj[mN_ - m + pa];
+                }
+            };
+
             if (MODE == MCQ_MODE_FULL3D || (step & 1) == 0) upkeep();
             bool batched;  // the batched draw below succeeded for this chain
             if constexpr (MODE == MCQ_MODE_BOARD) {
@@ -811,6 +823,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN), c5 = (int)(w5 & maskN);
                 cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
                 old_k = hts[cell];
+                if constexpr (PACKED) load_probes();
                 const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
                 pc = use3 ? c3 : use4 ? c4 : c5;
                 const uint32_t kp = (uint32_t)(use3 ? p3 : use4 ? p4 : p5);
@@ -848,7 +861,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 rng.pos += batched ? (free1 ? p3 : p6) + 3 : 0u;
             }
             if (wave_any(!batched)) {  // wave-uniform guard of the rare path
-                if (!batched) sequential();
+                if (!batched) {
+                    sequential();
+                    if constexpr (PACKED) load_probes();
+                }
             }
 
             STAMP(2);  // proposal draws
@@ -895,8 +911,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     uint32_t accp = 0;
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
-                        const int m = pm[t], mN_ = __mul24(m, N);
-                        const uint32_t hr = hrow[m], hc = hj[mN_], hdg = hd[mN_ + m], han = ha[mN_ - m];
+                        const int m = pm[t];
+                        const uint32_t hr = ph[4 * t], hc = ph[4 * t + 1], hdg = ph[4 * t + 2], han = ph[4 * t + 3];
                         const uint32_t Mr = pk_star(BB, abs_diff(m, j)), Mc = pk_star(BB, abs_diff(m, i));
                         const uint32_t vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1) & 0x00010001u;
                         const uint32_t va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1) & 0x00010001u;
