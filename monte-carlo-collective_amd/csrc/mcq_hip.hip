@@ -784,7 +784,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             };
 
-            // packed dE probes: the probed heights depend on (i, j) only and are requested together with the old height
+            // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
+            // the old height (with four, the 16 extra live registers would spill)
+            constexpr bool EARLY_PROBES = PACKED && NT == 3;
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN), c5 = (int)(w5 & maskN);
                 cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
                 old_k = hts[cell];
-                if constexpr (PACKED) load_probes();
+                if constexpr (EARLY_PROBES) load_probes();
                 const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
                 pc = use3 ? c3 : use4 ? c4 : c5;
                 const uint32_t kp = (uint32_t)(use3 ? p3 : use4 ? p4 : p5);
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             if (wave_any(!batched)) {  // wave-uniform guard of the rare path
                 if (!batched) {
                     sequential();
-                    if constexpr (PACKED) load_probes();
+                    if constexpr (EARLY_PROBES) load_probes();
                 }
             }
 
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     const uint32_t BB = Bo | (Bn << 16);
                     const uint32_t shd = (uint32_t)(dji + 16), sha = (uint32_t)sij;
                     uint32_t accp = 0;
+                    if constexpr (!EARLY_PROBES) load_probes();
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
                         const int m = pm[t];
@@ -1259,13 +1262,16 @@ int launch_sweep(const KArgs& a, hipStream_t s) {
 
 template <int MODE, int G>
 int launch_sweep_g(const KArgs& a, hipStream_t s) {
-    const bool pat = MODE == MCQ_MODE_BOARD && a.patience >= 0;
+    if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
+        return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
+    }
+    const bool pat = a.patience >= 0;
     if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
-    if (MODE == MCQ_MODE_BOARD && G == 4 && !pat) {  // straight-line probe blocks for the common board sizes
+    if constexpr (MODE == MCQ_MODE_BOARD && G == 4) {  // straight-line probe blocks for the common board sizes
         const int nt = (a.N + G - 1) / G;
-        if (nt == 3) return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
-        if (nt == 4) return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16
-        if (nt == 6) return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
+        if (!pat && nt == 3) return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
+        if (!pat && nt == 4) return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16
+        if (!pat && nt == 6) return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
     }
     return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
 }
