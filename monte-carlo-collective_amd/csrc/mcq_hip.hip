@@ -43,6 +43,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/mcq.h"
 
@@ -92,6 +93,7 @@ struct KArgs {
     int state_bytes;
     int rec_words;          // words per chain record in the workspace
     int chain_lds_words;    // words of LDS per chain in the sweep kernel
+    int full_pad;           // full_3d: spare column words on either side of the column table (>= N-1: out-of-board diagonal probes)
     double beta_const, beta_start, beta_end;
     long long n_steps, n_chains, patience, hist_stride, bits_stride;
     uint32_t* ws;           // chain records
@@ -368,6 +370,13 @@ __device__ __forceinline__ uint32_t pk_star(uint32_t bb, uint32_t d) {
     return bb | __builtin_bit_cast(uint32_t, l) | __builtin_bit_cast(uint32_t, r);
 }
 
+// the same with a shift distance per half (dd = d_low | d_high << 16)
+__device__ __forceinline__ uint32_t pk_star2(uint32_t bb, uint32_t dd) {
+    const u16x2 v = __builtin_bit_cast(u16x2, bb), d = __builtin_bit_cast(u16x2, dd);
+    const u16x2 l = v << d, r = v >> d;
+    return bb | __builtin_bit_cast(uint32_t, l) | __builtin_bit_cast(uint32_t, r);
+}
+
 // DPP reductions over the G lanes of a group (G = 4, 8 or 16), result in every lane of the group.
 template <int G>
 __device__ __forceinline__ int group_sum(int v) {
@@ -562,12 +571,12 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
 }
 
 // LDS per chain: stage[16] | ring[64 + 32 mirrored] | board: pad, heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
-//                full_3d: pad[32], column words [Q], pad[32], queens uint16 [Q]
+//                full_3d: pad[full_pad], column words [Q], pad[full_pad], queens uint16 [Q]; column words are uint16 in the
+//                unrolled variants (N <= 16), uint32 otherwise
 // (the staging block sits in front of the ring so that ring[-1], which an unused draw position may address, is the chain's own)
 constexpr int LDS_STAGE = 0;                          // word offset of the energy_history staging block
 constexpr int LDS_RING = 16;                          // word offset of the ring
 constexpr int LDS_STATE = LDS_RING + RING + RING_MIRROR;  // word offset of the state
-constexpr int FULL_PAD = 32;               // full_3d: spare words on either side of the column words (N <= 32)
 
 // trace == REDUCED: add the block of 16 history entries [e0, e0 + 16) of the wavefront's chains to the per-entry
 // accumulators.  A stage word is E | accepted << 31; entry e of a chain counts iff e < hist_len (chains that stopped
@@ -635,8 +644,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     uint8_t* hts = (uint8_t*)(base + LDS_STATE + (N + 2) / 4);  // board (the diagonal probes read up to N-1 bytes outside either end)
     // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
     // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
-    uint32_t* colw = base + LDS_STATE + FULL_PAD;
-    uint16_t* qn = (uint16_t*)(colw + Q + FULL_PAD);
+    constexpr bool NARROW = MODE == MCQ_MODE_FULL3D && NT > 0;  // N <= 16: 16-bit column words
+    typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type colw_t;
+    colw_t* colw = (colw_t*)(base + LDS_STATE) + a.full_pad;
+    uint16_t* qn = (uint16_t*)(colw + Q + a.full_pad);
 
     // ---- load the chain record ----
     uint32_t* rec = a.ws + crow * (long long)a.rec_words;
@@ -644,11 +655,15 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     if (MODE == MCQ_MODE_BOARD) {
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
     } else {
-        for (int w = gl; w < Q; w += G) colw[w] = 0;
+        uint32_t* cw32 = base + LDS_STATE;  // the column table and its pads as 32-bit words
+        const int cwords = (int)((2 * a.full_pad + Q) * sizeof(colw_t) / 4);
+        for (int w = gl; w < cwords; w += G) cw32[w] = 0;
         for (int c = gl; c < Q; c += G) {
             const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
             qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
-            atomicOr(&colw[qi_ * N + qj_], 1u << qk_);
+            const uint32_t e = (uint32_t)a.full_pad + qi_ * N + qj_;  // element index from the start of the table
+            if (NARROW) atomicOr(&cw32[e >> 1], (1u << qk_) << ((e & 1u) * 16u));
+            else atomicOr(&cw32[e], 1u << qk_);
         }
     }
     const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
@@ -688,22 +703,24 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)a.c32_tab;
     const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)a.beta_tab;
 
-    // Packed dE probes (board, N = 9..16 <=> NT = 3 or 4): lane constants of the NT columns / rows this lane probes.
-    //   pm      probe index m = gl + t*G, clamped into the board (a clamped probe has all-zero selectors below)
-    //   krc     selector of the row / column probe: one bit per half
+    // Packed dE probes (N = 9..16 <=> NT = 3 or 4): lane constants of the NT columns / rows this lane probes.  Board: the G
+    // lanes of a chain share the 4N probes; full_3d: half of the lanes probe around the new cell, the other half around the old.
+    //   pm      probe index m, clamped into the board (a clamped probe has all-zero selectors below)
+    //   krc     selector of the row / column probe (board: one bit per half; full_3d: everything)
     //   vdm     bit (j - i + 16) set iff the diagonal probe (m, m - i + j) is on the board
     //   vam     bit (i + j) set iff the anti-diagonal probe (m, i + j - m) is
-    constexpr bool PACKED = MODE == MCQ_MODE_BOARD && (NT == 3 || NT == 4);
+    constexpr bool PACKED = (MODE == MCQ_MODE_BOARD && (NT == 3 || NT == 4)) || NARROW;
+    constexpr int PG = NARROW ? G / 2 : G;  // lanes that share one set of probes
     constexpr int NTP = PACKED ? NT : 1;
     int pm[NTP];
     uint32_t krc[NTP], vdm[NTP], vam[NTP];
 #pragma unroll
     for (int t = 0; t < NTP; t++) {
-        const int m = gl + t * G;
+        const int m = (gl & (PG - 1)) + t * PG;
         const bool inb = m < N;
         const uint32_t full = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
         pm[t] = inb ? m : N - 1;
-        krc[t] = inb ? 0x00010001u : 0u;
+        krc[t] = inb ? (NARROW ? 0xffffffffu : 0x00010001u) : 0u;
         vdm[t] = inb && PACKED ? full << ((16 - pm[t]) & 31) : 0u;
         vam[t] = inb && PACKED ? full << (pm[t] & 31) : 0u;
     }
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 
             // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
             // the old height (with four, the 16 extra live registers would spill)
-            constexpr bool EARLY_PROBES = PACKED && NT == 3;
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT == 3;
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);
@@ -837,19 +854,20 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 // accepted for randint(0, N) after it (the second is used when the first cell is occupied);
                 // the uniform's two words follow the chosen triple.
                 const uint32_t s = rng.pos & (RING - 1);
-                const uint32_t top = 0x80000000u;
                 const uint32_t vq = rng.view(rng.okq_lo, rng.okq_hi, s);
-                const uint32_t pq = __builtin_ctz(vq | top);
-                const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << pq);
+                const int pq = __ffs((int)vq) - 1;  // an empty mask gives -1, like the positions below (view_ok is false then)
+                const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
                 const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                 const bool view_ok = vq != 0 && (n6 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
-                const uint32_t p1 = __builtin_ctz(n1 | top), p2 = __builtin_ctz(n2 | top), p3 = __builtin_ctz(n3 | top);
-                const uint32_t p4 = __builtin_ctz(n4 | top), p5 = __builtin_ctz(n5 | top), p6 = __builtin_ctz(n6 | top);
-                const uint32_t wq = ring[(s + pq) & (RING - 1)];
-                const uint32_t w1 = ring[(s + p1) & (RING - 1)], w2 = ring[(s + p2) & (RING - 1)], w3 = ring[(s + p3) & (RING - 1)];
-                const uint32_t w4 = ring[(s + p4) & (RING - 1)], w5 = ring[(s + p5) & (RING - 1)], w6 = ring[(s + p6) & (RING - 1)];
-                const uint32_t u31 = ring[(s + p3 + 1) & (RING - 1)], u32 = ring[(s + p3 + 2) & (RING - 1)];
-                const uint32_t u61 = ring[(s + p6 + 1) & (RING - 1)], u62 = ring[(s + p6 + 2) & (RING - 1)];
+                const int p1 = __ffs((int)n1) - 1, p2 = __ffs((int)n2) - 1, p3 = __ffs((int)n3) - 1;
+                const int p4 = __ffs((int)n4) - 1, p5 = __ffs((int)n5) - 1, p6 = __ffs((int)n6) - 1;
+                // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
+                const uint32_t* rs = ring + s;
+                const uint32_t wq = rs[pq];
+                const uint32_t w1 = rs[p1], w2 = rs[p2], w4 = rs[p4], w5 = rs[p5];
+                const uint32_t *r3 = rs + p3, *r6 = rs + p6;
+                const uint32_t w3 = r3[0], u31 = r3[1], u32 = r3[2];
+                const uint32_t w6 = r6[0], u61 = r6[1], u62 = r6[2];
                 const uint32_t vqi = wq & maskQ;
                 qi = (int)(vqi <= mQ ? vqi : 0u);  // an unused attempt must still index inside the queen table
                 oldp = qn[qi];
@@ -860,7 +878,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
                 uw1 = free1 ? u31 : u61, uw2 = free1 ? u32 : u62;
                 batched = view_ok && (free1 || free2);
-                rng.pos += batched ? (free1 ? p3 : p6) + 3 : 0u;
+                rng.pos += batched ? (uint32_t)(free1 ? p3 : p6) + 3u : 0u;
             }
             if (wave_any(!batched)) {  // wave-uniform guard of the rare path
                 if (!batched) {
@@ -945,7 +963,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const uint32_t Bo = 1u << ok_, Bn = 1u << nk;
                 auto star = [&](int m, bool in_board, int ci, int cj, uint32_t B) {
                     const int mN_ = __mul24(m, N);
-                    const uint32_t* cw = colw + mN_;
+                    const colw_t* cw = colw + mN_;
                     const int jd = m - ci + cj, ja = ci + cj - m;
                     const uint32_t wr = colw[__mul24(ci, N) + m], wc = cw[cj], wd = cw[jd], wa = cw[ja];
                     const uint32_t dr = abs_diff(m, cj), dc = abs_diff(m, ci);
@@ -956,7 +974,29 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     return in_board ? c : 0;
                 };
                 int part = 0;
-                if constexpr (NT > 0) {
+                if constexpr (NARROW) {
+                    // Half of the chain's lanes probe around the new cell, the other half around the old one (which counts
+                    // negative).  A lane packs the row and the column probe of its index m into one register (masks from one
+                    // pk_star2 with the two distances), and the two diagonal probes into another (both at the column distance).
+                    const bool oldside = gl >= PG;
+                    const int ci = oldside ? oi : ni, cj = oldside ? oj : nj;
+                    const uint32_t B = oldside ? Bo : Bn, BB = B | (B << 16);
+                    const uint32_t shd = (uint32_t)(cj - ci + 16), sha = (uint32_t)(ci + cj);
+                    const colw_t* crow = colw + __mul24(ci, N);
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const int m = pm[t];
+                        const colw_t* cw = colw + __mul24(m, N);
+                        const uint32_t wr = crow[m], wc = cw[cj], wd = cw[m - ci + cj], wa = cw[ci + cj - m];
+                        const uint32_t Mrc = pk_star2(BB, abs_diff(m, cj) | (abs_diff(m, ci) << 16));
+                        const uint32_t Mcc = __builtin_amdgcn_perm(Mrc, Mrc, 0x03020302u);  // the column-distance mask in both halves
+                        const uint32_t vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1), va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1);
+                        cnt += __popc((wr | (wc << 16)) & Mrc & krc[t]);
+                        cnt += __popc(((wd & vd) | ((wa & va) << 16)) & Mcc);
+                    }
+                    part = oldside ? -(int)cnt : (int)cnt;
+                } else if constexpr (NT > 0) {
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
                         const int m = gl + t * G;
@@ -1004,10 +1044,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 hts[cell] = (uint8_t)(acc ? pc : old_k);  // every lane of the group writes the same byte; a rejected move rewrites the old height
             } else if (acc) {
                 // mcmc.py:171-183; every lane of the group performs the same read-modify-writes
-                uint32_t* wo = colw + __mul24((int)(oldp & 31), N) + (int)((oldp >> 5) & 31);
-                *wo &= ~(1u << ((oldp >> 10) & 31));
-                uint32_t* wn = colw + __mul24(pa, N) + pb;
-                *wn |= 1u << pc;
+                colw_t* wo = colw + __mul24((int)(oldp & 31), N) + (int)((oldp >> 5) & 31);
+                *wo = (colw_t)(*wo & ~(1u << ((oldp >> 10) & 31)));
+                colw_t* wn = colw + __mul24(pa, N) + pb;
+                *wn = (colw_t)(*wn | (1u << pc));
                 qn[qi] = (uint16_t)newp;
             }
             E += acc ? dE : 0;
@@ -1212,6 +1252,16 @@ size_t c32_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p-
 long long red_len_for(const mcq_params* p) { return (p->n_steps + 1 + 31) & ~31LL; }
 size_t red_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 4 * red_len_for(p) * 8 : 0; }
 
+// LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
+// side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
+int chain_lds_words_for(int N, int mode, bool narrow) {
+    const int Q = N * N, pad = (N + 3) & ~3;
+    int w = LDS_STATE;
+    if (mode == MCQ_MODE_BOARD) w += 2 * ((N + 2) / 4) + (Q + 3) / 4;
+    else w += (narrow ? (2 * pad + Q + 1) / 2 : 2 * pad + Q) + (Q + 1) / 2;
+    return (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
+}
+
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
     memset(a, 0, sizeof *a);
     a->N = p->N, a->Q = p->N * p->N, a->mode = p->mode, a->init = p->init, a->sched = p->sched, a->flags = p->flags;
@@ -1229,8 +1279,8 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->rec_words = rec_words_for(p);
     // board: the diagonal probes read up to N-1 bytes before / after the heights; (N+2)/4 spare words on each
     // side keep those (discarded) reads inside the chain's own LDS slice.
-    a->chain_lds_words = LDS_STATE + (p->mode == MCQ_MODE_BOARD ? 2 * ((p->N + 2) / 4) + (a->Q + 3) / 4 : FULL_PAD + a->Q + FULL_PAD + (a->Q + 1) / 2);
-    a->chain_lds_words = (a->chain_lds_words + 3) & ~3;  // 16-byte multiple: the staging block is read with ds_read_b128
+    a->full_pad = (p->N + 3) & ~3;
+    a->chain_lds_words = chain_lds_words_for(p->N, p->mode, false);  // full_3d: the launcher picks the 16-bit layout where it applies
     a->beta_const = p->beta_const, a->beta_start = p->beta_start, a->beta_end = p->beta_end;
     a->n_steps = p->n_steps, a->n_chains = p->n_chains;
     a->patience = p->mode == MCQ_MODE_BOARD ? p->patience : -1;  // full_3d ignores early_stop_patience (experiments.py:199-279)
@@ -1263,17 +1313,26 @@ int launch_sweep(const KArgs& a, hipStream_t s) {
 template <int MODE, int G>
 int launch_sweep_g(const KArgs& a, hipStream_t s) {
     if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
+        if constexpr (G == 8) {  // N = 9..16: 16-bit column words, four lanes around each of the two cells
+            const int nt = (a.N + 3) / 4;
+            if (!a.red && (nt == 3 || nt == 4)) {
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+                return nt == 3 ? launch_sweep<MODE, G, false, 3, false>(b, s) : launch_sweep<MODE, G, false, 4, false>(b, s);
+            }
+        }
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
+    } else {
+        const bool pat = a.patience >= 0;
+        if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
+        if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
+            const int nt = (a.N + G - 1) / G;
+            if (!pat && nt == 3) return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
+            if (!pat && nt == 4) return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16
+            if (!pat && nt == 6) return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
+        }
+        return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     }
-    const bool pat = a.patience >= 0;
-    if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
-    if constexpr (MODE == MCQ_MODE_BOARD && G == 4) {  // straight-line probe blocks for the common board sizes
-        const int nt = (a.N + G - 1) / G;
-        if (!pat && nt == 3) return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
-        if (!pat && nt == 4) return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16
-        if (!pat && nt == 6) return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
-    }
-    return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
 }
 
 template <int MODE>
