@@ -53,6 +53,16 @@ CASES = [
     (16, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 800, 20, None),
     (21, "board", "random", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 600, 9, None),
     (25, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 400, 7, None),
+    (11, "board", "random", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 900, 14, None),
+    (14, "board", "random", {"type": "logarithmic_annealing", "beta_start": 0.5, "beta_end": 3.0}, 800, 13, None),
+    (15, "board", "latin", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 700, 10, None),
+    # full_3d sizes of the 16-bit column-word variants (N = 9..16 at 8 lanes per chain), with and without clamped probe lanes
+    (9, "full_3d", "random", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}, 700, 13, None),
+    (10, "full_3d", "klarner", {"type": "constant", "beta_const": 1.0}, 600, 9, None),
+    (13, "full_3d", "latin", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 600, 9, None),
+    (15, "full_3d", "random", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 500, 7, None),
+    (16, "full_3d", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 500, 10, None),
+    (17, "full_3d", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 300, 6, None),
     # largest supported boards: 64 KB permutation array in the init kernel, 5-bit coordinate packing, bit 31 of the masks
     (32, "full_3d", "random", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 2.0}, 150, 3, None),
     (31, "board", "klarner", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 300, 5, 80),
