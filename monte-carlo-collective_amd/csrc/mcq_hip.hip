@@ -703,13 +703,13 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)a.c32_tab;
     const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)a.beta_tab;
 
-    // Packed dE probes (N = 9..16 <=> NT = 3 or 4): lane constants of the NT columns / rows this lane probes.  Board: the G
+    // Packed dE probes (N <= 16 <=> NT <= 4): lane constants of the NT columns / rows this lane probes.  Board: the G
     // lanes of a chain share the 4N probes; full_3d: half of the lanes probe around the new cell, the other half around the old.
     //   pm      probe index m, clamped into the board (a clamped probe has all-zero selectors below)
     //   krc     selector of the row / column probe (board: one bit per half; full_3d: everything)
     //   vdm     bit (j - i + 16) set iff the diagonal probe (m, m - i + j) is on the board
     //   vam     bit (i + j) set iff the anti-diagonal probe (m, i + j - m) is
-    constexpr bool PACKED = (MODE == MCQ_MODE_BOARD && (NT == 3 || NT == 4)) || NARROW;
+    constexpr bool PACKED = (MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 4) || NARROW;  // N <= 16
     constexpr int PG = NARROW ? G / 2 : G;  // lanes that share one set of probes
     constexpr int NTP = PACKED ? NT : 1;
     int pm[NTP];
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 
             // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
             // the old height (with four, the 16 extra live registers would spill)
-            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT == 3;
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3;
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);
@@ -1313,12 +1313,17 @@ int launch_sweep(const KArgs& a, hipStream_t s) {
 template <int MODE, int G>
 int launch_sweep_g(const KArgs& a, hipStream_t s) {
     if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
-        if constexpr (G == 8) {  // N = 9..16: 16-bit column words, four lanes around each of the two cells
+        if constexpr (G == 8) {  // N <= 16: 16-bit column words, four lanes around each of the two cells
             const int nt = (a.N + 3) / 4;
-            if (!a.red && (nt == 3 || nt == 4)) {
+            if (!a.red && nt <= 4) {
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
-                return nt == 3 ? launch_sweep<MODE, G, false, 3, false>(b, s) : launch_sweep<MODE, G, false, 4, false>(b, s);
+                switch (nt) {
+                case 1: return launch_sweep<MODE, G, false, 1, false>(b, s);
+                case 2: return launch_sweep<MODE, G, false, 2, false>(b, s);
+                case 3: return launch_sweep<MODE, G, false, 3, false>(b, s);
+                default: return launch_sweep<MODE, G, false, 4, false>(b, s);
+                }
             }
         }
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
@@ -1326,10 +1331,15 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         const bool pat = a.patience >= 0;
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
-            const int nt = (a.N + G - 1) / G;
-            if (!pat && nt == 3) return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
-            if (!pat && nt == 4) return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16
-            if (!pat && nt == 6) return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
+            if (!pat) switch ((a.N + G - 1) / G) {
+                case 1: return launch_sweep<MODE, G, false, 1, false>(a, s);  // N = 2..4
+                case 2: return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 5..8
+                case 3: return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
+                case 4: return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16 (up to here: packed 16-bit masks)
+                case 5: return launch_sweep<MODE, G, false, 5, false>(a, s);  // N = 17..20
+                case 6: return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
+                default: break;
+                }
         }
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     }

@@ -63,6 +63,16 @@ CASES = [
     (15, "full_3d", "random", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 500, 7, None),
     (16, "full_3d", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 500, 10, None),
     (17, "full_3d", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 300, 6, None),
+    # every unrolled variant: board ceil(N/4) = 1..6, full_3d ceil(N/4) = 1..4
+    (4, "board", "random", {"type": "constant", "beta_const": 1.5}, 600, 9, None),
+    (6, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 800, 11, None),
+    (8, "board", "klarner", {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, 800, 10, None),
+    (18, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 500, 8, None),
+    (20, "board", "klarner", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 500, 6, None),
+    (3, "full_3d", "random", {"type": "constant", "beta_const": 1.0}, 600, 9, None),
+    (4, "full_3d", "latin", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}, 600, 9, None),
+    (6, "full_3d", "random", {"type": "logarithmic_annealing", "beta_start": 0.5, "beta_end": 3.0}, 700, 12, None),
+    (8, "full_3d", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 700, 10, None),
     # largest supported boards: 64 KB permutation array in the init kernel, 5-bit coordinate packing, bit 31 of the masks
     (32, "full_3d", "random", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 2.0}, 150, 3, None),
     (31, "board", "klarner", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 300, 5, 80),
