@@ -803,7 +803,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 
             // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
             // the old height (with four, the 16 extra live registers would spill)
-            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3;
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3 && !REDUCED;
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);
@@ -1329,18 +1329,20 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     } else {
         const bool pat = a.patience >= 0;
-        if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
             if (!pat) switch ((a.N + G - 1) / G) {
-                case 1: return launch_sweep<MODE, G, false, 1, false>(a, s);  // N = 2..4
-                case 2: return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 5..8
-                case 3: return launch_sweep<MODE, G, false, 3, false>(a, s);  // N = 9..12
-                case 4: return launch_sweep<MODE, G, false, 4, false>(a, s);  // N = 13..16 (up to here: packed 16-bit masks)
-                case 5: return launch_sweep<MODE, G, false, 5, false>(a, s);  // N = 17..20
-                case 6: return launch_sweep<MODE, G, false, 6, false>(a, s);  // N = 21..24
+#define MCQ_NT_CASE(nt) case nt: return a.red ? launch_sweep<MODE, G, false, (nt == 4 ? 0 : nt), true>(a, s) : launch_sweep<MODE, G, false, nt, false>(a, s)
+                MCQ_NT_CASE(1);  // N = 2..4
+                MCQ_NT_CASE(2);  // N = 5..8
+                MCQ_NT_CASE(3);  // N = 9..12
+                MCQ_NT_CASE(4);  // N = 13..16 (up to here: packed 16-bit masks; the reduced-trace variant would spill and takes the loop)
+                MCQ_NT_CASE(5);  // N = 17..20
+                MCQ_NT_CASE(6);  // N = 21..24
+#undef MCQ_NT_CASE
                 default: break;
                 }
         }
+        if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     }
 }

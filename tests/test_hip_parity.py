@@ -207,7 +207,8 @@ def test_reduced_trace_equals_statistics_of_the_full_trace():
     run of the same chains, with and without early stops, for every lane width, ragged chain counts included."""
     sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
     for mode, N, patience, n_steps, n_chains in (("board", 8, None, 1000, 77), ("board", 8, 60, 1500, 77), ("board", 12, None, 333, 16),
-                                                   ("full_3d", 6, None, 700, 41)):
+                                                   ("full_3d", 6, None, 700, 41), ("board", 4, None, 300, 9), ("board", 16, None, 300, 9),
+                                                   ("board", 18, None, 200, 7), ("board", 22, None, 200, 6), ("full_3d", 12, None, 300, 10)):
         for lanes in LANES:
             p = abi.make_params(N, n_steps, "random", sp, n_chains, mcmc_type=mode, early_stop_patience=patience, lanes_per_chain=lanes)
             seeds = abi.seeds_for(11, n_chains)
