@@ -64,7 +64,7 @@ def main():
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MCQ_BENCH_FORCE_DIST") == "1":  # the override exercises the RCCL path on a one-GPU box
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

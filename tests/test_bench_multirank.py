@@ -37,3 +37,20 @@ def test_two_ranks_equal_one_rank():
     for k in ("min_energy", "mean_best_energy", "acceptance_rate"):  # same 8192 chains, same seeds, however they are split
         assert two[k] == one[k], k
     assert two["scaling"] == "weak" and two["unit"] == "moves/s" and two["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rccl_path_single_rank():
+    """The real backend of the multi-GPU bench ("nccl" = RCCL, device-bound process group, device-side all-reduce and
+    barrier) on the one GPU of the box: a world of one rank launched exactly as the driver launches N of them."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    one = _bench({}, [sys.executable], 4096)
+    rccl = _bench({"MCQ_BENCH_FORCE_DIST": "1"},
+                  [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port)], 4096)
+    assert rccl["n_gpus"] == 1
+    for k in ("min_energy", "mean_best_energy", "acceptance_rate"):
+        assert rccl[k] == one[k], k
