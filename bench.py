@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_MOVE = 4.125  # one int32 energy_history entry + one accept bit
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2  # 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
 
 
 def main():
@@ -136,7 +137,8 @@ def main():
     algo_bytes = ALGO_BYTES_PER_MOVE * local_moves if trace else 0.0
     achieved = algo_bytes / (sweep_avg_ms * 1e-3) / 1e9
 
-    traffic = None
+    # PMC figures of this exact workload collected in separate rocprofv3 --pmc passes (tools/pmc_collect.sh), per launch
+    traffic, valu_insts = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -144,8 +146,9 @@ def main():
                 tj = json.load(f)
             key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}"
             traffic = tj.get(key, {}).get("bytes_per_launch")
+            valu_insts = tj.get(key, {}).get("valu_insts_per_launch")
         except (OSError, ValueError):
-            traffic = None
+            traffic, valu_insts = None, None
 
     line = {
         "metric": "Metropolis moves/sec (whole node) + min-energy-reached, N=12 board MCMC",
@@ -183,6 +186,13 @@ def main():
             "note": "algorithmic bytes = 4.125 B/move (int32 trace entry + accept bit); the sweep is issue/latency bound, see DESIGN.md",
         },
     }
+    if valu_insts:
+        # the on-chip view of the same kernel: wave64 VALU instructions (PMC count of this workload) over the live kernel
+        # time, against one instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32) on 1024 SIMDs at 2.4 GHz
+        peak = VALU_PEAK_GINST
+        ach = valu_insts / (sweep_avg_ms * 1e-3) / 1e9
+        line["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                                          "per_move": valu_insts / max(1, local_moves)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker / baseline only; never on the measured path
