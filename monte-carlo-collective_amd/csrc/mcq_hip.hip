@@ -880,7 +880,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 batched = view_ok && (free1 || free2);
                 rng.pos += batched ? (uint32_t)(free1 ? p3 : p6) + 3u : 0u;
             }
-            if (wave_any(!batched)) {  // wave-uniform guard of the rare path
+            if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
                 if (!batched) {
                     sequential();
                     if constexpr (EARLY_PROBES) load_probes();
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 acc = acc || sure_acc;
                 exact = xneg && !sure_acc && !sure_rej;
             }
-            if (wave_any(exact)) {  // ~0.1 % of the steps of a chain
+            if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
                 if (exact) {
                     const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
                     acc = (r & 1) != 0, ties += r >> 1;
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             best = min(best, E);
             if (PATIENCE) no_imp = improved ? 0 : no_imp + 1;
             const int e = step + 1;
-            if (wave_any(improved)) {  // rare after the first few hundred steps
+            if (__builtin_expect(wave_any(improved), 0)) {  // rare after the first few hundred steps
                 if (improved) {
                     // first index of the minimum of energy_history (experiments.py:364-365); with patience 0 the chain stops
                     // right here without appending this entry (no_imp = 0 >= 0), so the index stays
