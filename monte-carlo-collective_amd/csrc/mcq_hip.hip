@@ -223,6 +223,14 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// index of the lowest set bit, -1 for zero, in one instruction (what __ffs(x) - 1 means, without the zero test the
+// compiler wraps around it)
+__device__ __forceinline__ int lowest_bit(uint32_t x) {
+    int p;
+    asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(x));
+    return p;
+}
+
 // |a - b| of two small non-negative integers in one instruction
 __device__ __forceinline__ uint32_t abs_diff(int a, int b) {
     uint32_t d;
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 // a fifth accepted word with the two words of the uniform still inside the view, and a full view
                 const bool view_ok = (v5 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
                 // an empty mask gives position -1 (view_ok is false then): the fetches below read ring[s - 1 ..], still the chain's own LDS
-                const int p1 = __ffs((int)v1) - 1, p2 = __ffs((int)v2) - 1, p3 = __ffs((int)v3) - 1, p4 = __ffs((int)v4) - 1, p5 = __ffs((int)v5) - 1;
+                const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5);
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  Each candidate for new_k is
                 // fetched together with the two words that follow it -- the uniform's words if it becomes new_k -- off one
                 // base address, so nothing has to wait for the old height (one LDS round trip less on the critical path).
@@ -855,12 +863,11 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 // the uniform's two words follow the chosen triple.
                 const uint32_t s = rng.pos & (RING - 1);
                 const uint32_t vq = rng.view(rng.okq_lo, rng.okq_hi, s);
-                const int pq = __ffs((int)vq) - 1;  // an empty mask gives -1, like the positions below (view_ok is false then)
+                const int pq = lowest_bit(vq);  // an empty mask gives -1, like the positions below (view_ok is false then)
                 const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
                 const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                 const bool view_ok = vq != 0 && (n6 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
-                const int p1 = __ffs((int)n1) - 1, p2 = __ffs((int)n2) - 1, p3 = __ffs((int)n3) - 1;
-                const int p4 = __ffs((int)n4) - 1, p5 = __ffs((int)n5) - 1, p6 = __ffs((int)n6) - 1;
+                const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3), p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6);
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
                 const uint32_t* rs = ring + s;
                 const uint32_t wq = rs[pq];
