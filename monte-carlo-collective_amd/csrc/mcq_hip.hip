@@ -1027,17 +1027,20 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             // ---- accept iff u < min(1, exp(-beta dE)); the uniform is always drawn -------------------
             // x = -beta dE < 0 iff beta and dE have the same sign (c32 has the sign of -beta); otherwise
             // the probability is 1 (also for a NaN beta, like min(1.0, nan) in the reference).
-            const bool xneg = (c32 < 0.0f && dE > 0) || (c32 > 0.0f && dE < 0);
-            bool acc = !xneg, exact = xneg;
-            if (!exact_only) {
-                // u * 2^27 lies in [a27, a27 + 1); e27 = exp(x) * 2^27 within 3e-5 relative
-                const float fa = (float)(uw1 >> 5);
-                const float e27 = __builtin_amdgcn_exp2f(fmaf((float)dE, c32, 27.0f));
-                const bool sure_acc = fa + 1.0f < e27 * 0.9990234375f;
-                const bool sure_rej = fa > e27 * 1.0009765625f;
-                acc = acc || sure_acc;
-                exact = xneg && !sure_acc && !sure_rej;
-            }
+            // sgn (wave-uniform, from the bits of c32): +1 for beta > 0, -1 for beta < 0, 0 for a zero or NaN beta
+            const uint32_t cbits = __float_as_uint(c32), cmag = cbits & 0x7fffffffu;
+            const int sgn = (cmag == 0u || cmag > 0x7f800000u) ? 0 : ((cbits >> 31) ? 1 : -1);
+            const bool xneg = __mul24(dE, sgn) > 0;
+            // u * 2^27 lies in [a27, a27 + 1), a27 = the top 27 bits of u; e27 = exp(x) * 2^27 within 3e-5 relative.
+            // d = a27 + 1/2 - e27 and the half-width w = e27 * 2^-10 + 1/2: d < -w accepts for sure (a27 + 1 < e27 (1 - 2^-10)),
+            // d > w rejects for sure (a27 > e27 (1 + 2^-10)), in between the float64 path decides.  Both tests end in one
+            // compare whose operand carries the x < 0 condition, so each result is a lane mask straight from the compare.
+            const float fa = (float)(uw1 >> 5);
+            const float e27 = __builtin_amdgcn_exp2f(fmaf((float)dE, c32, 27.0f));
+            const float d = (fa + 0.5f) - e27;
+            const float w = exact_only ? 3.0e38f : fmaf(e27, 0.0009765625f, 0.5f);
+            bool exact = __builtin_fabsf(d) <= (xneg ? w : -1.0f);
+            bool acc = (xneg ? d : -1.0f) < 0.0f;
             if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
                 if (exact) {
                     const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
