@@ -73,6 +73,11 @@ CASES = [
     (4, "full_3d", "latin", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}, 600, 9, None),
     (6, "full_3d", "random", {"type": "logarithmic_annealing", "beta_start": 0.5, "beta_end": 3.0}, 700, 12, None),
     (8, "full_3d", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 700, 10, None),
+    # signs and magnitudes of beta: negative (uphill moves are the certain ones), through zero, and so large that exp underflows
+    (6, "board", "random", {"type": "constant", "beta_const": -0.7}, 600, 9, None),
+    (6, "full_3d", "random", {"type": "linear_annealing", "beta_start": -1.0, "beta_end": 2.0}, 600, 9, None),
+    (8, "board", "random", {"type": "constant", "beta_const": 40.0}, 600, 9, None),
+    (7, "full_3d", "random", {"type": "exponential_annealing", "beta_start": 1e-30, "beta_end": 1e-3}, 500, 7, None),
     # largest supported boards: 64 KB permutation array in the init kernel, 5-bit coordinate packing, bit 31 of the masks
     (32, "full_3d", "random", {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 2.0}, 150, 3, None),
     (31, "board", "klarner", {"type": "sinusoidal_annealing", "beta_start": 0.5, "beta_end": 3.0}, 300, 5, 80),
