@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             };
 
-            if (MODE == MCQ_MODE_FULL3D || (step & 1) == 0) upkeep();
+            const bool upkeep_now = MODE == MCQ_MODE_FULL3D || (step & 1) == 0;
             bool batched;  // the batched draw below succeeded for this chain
             if constexpr (MODE == MCQ_MODE_BOARD) {
                 // Straight-line for every chain of the wavefront (no divergent branch): positions of the next four
@@ -833,10 +833,11 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const uint32_t s = rng.pos & (RING - 1);
                 const uint32_t v1 = rng.view(rng.ok_lo, rng.ok_hi, s);
                 const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
-                // a fifth accepted word with the two words of the uniform still inside the view, and a full view
-                const bool view_ok = (v5 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
+                const uint32_t avail = rng.gen - rng.pos;  // ring slots [pos, pos + avail) hold words; accept bits beyond them are stale
                 // an empty mask gives position -1 (view_ok is false then): the fetches below read ring[s - 1 ..], still the chain's own LDS
                 const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5);
+                // a fifth accepted word whose two followers are still inside the view and inside the generated words
+                const bool view_ok = (v5 & 0x3fffffffu) != 0 && (uint32_t)(p5 + 2) < avail && !force_slow;
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  Each candidate for new_k is
                 // fetched together with the two words that follow it -- the uniform's words if it becomes new_k -- off one
                 // base address, so nothing has to wait for the old height (one LDS round trip less on the critical path).
@@ -846,6 +847,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const uint32_t w3 = r3[0], u31 = r3[1], u32 = r3[2];
                 const uint32_t w4 = r4[0], u41 = r4[1], u42 = r4[2];
                 const uint32_t w5 = r5[0], u51 = r5[1], u52 = r5[2];
+                // the stream upkeep runs while those reads are in flight; it appends behind the words of this view
+                if (upkeep_now) upkeep();
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
                 const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN), c5 = (int)(w5 & maskN);
                 cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
@@ -866,8 +869,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const int pq = lowest_bit(vq);  // an empty mask gives -1, like the positions below (view_ok is false then)
                 const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
                 const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
-                const bool view_ok = vq != 0 && (n6 & 0x3fffffffu) != 0 && rng.gen - rng.pos >= 32u && !force_slow;
+                const uint32_t avail = rng.gen - rng.pos;
                 const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3), p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6);
+                const bool view_ok = vq != 0 && (n6 & 0x3fffffffu) != 0 && (uint32_t)(p6 + 2) < avail && !force_slow;
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
                 const uint32_t* rs = ring + s;
                 const uint32_t wq = rs[pq];
@@ -875,6 +879,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 const uint32_t *r3 = rs + p3, *r6 = rs + p6;
                 const uint32_t w3 = r3[0], u31 = r3[1], u32 = r3[2];
                 const uint32_t w6 = r6[0], u61 = r6[1], u62 = r6[2];
+                if (upkeep_now) upkeep();  // while those reads are in flight
                 const uint32_t vqi = wq & maskQ;
                 qi = (int)(vqi <= mQ ? vqi : 0u);  // an unused attempt must still index inside the queen table
                 oldp = qn[qi];
