@@ -47,7 +47,10 @@ def lib():
     if _lib is None:
         _share_torch_hip_runtime()
         so = _build.SO
-        if _build.stale():
+        diag = os.environ.get("MCQ_DIAG_LIB")  # a diagnostic build of the same library (tools/stamp_profile.sh); never the oracle
+        if diag:
+            so = diag
+        elif _build.stale():
             try:
                 _build.build()
             except RuntimeError as e:

@@ -53,6 +53,22 @@ namespace {
 
 // Diagnostic build (-DMCQ_STAMPS, tools/stamp_profile.sh): s_memtime stamps around the sections of a Metropolis
 // step; the per-section cycle sums of every wavefront go to a debug buffer.  Never defined in the shipped library.
+// Diagnostic build (-DMCQ_WAVE_TIMES): start / end time (100 MHz s_memrealtime) and placement of every wavefront of the sweep.
+#ifdef MCQ_WAVE_TIMES
+#define WAVE_T0 const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime()
+#define WAVE_T1(buf)                                                                                         \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && (buf)) {                                                                     \
+            unsigned long long* r = (buf) + 4ull * blockIdx.x;                                               \
+            r[0] = wt0, r[1] = __builtin_amdgcn_s_memrealtime();                                             \
+            r[2] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20), r[3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); \
+        }                                                                                                    \
+    } while (0)
+#else
+#define WAVE_T0
+#define WAVE_T1(buf)
+#endif
+
 #ifdef MCQ_STAMPS
 #define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k)                                                        \
@@ -93,6 +109,7 @@ struct KArgs {
     int state_bytes;
     int rec_words;          // words per chain record in the workspace
     int chain_lds_words;    // words of LDS per chain in the sweep kernel
+    uint32_t* pace;         // progress table: one row of 16 words per SIMD of the device, word = step reached by the wavefront in that slot
     int full_pad;           // full_3d: spare column words on either side of the column table (>= N-1: out-of-board diagonal probes)
     double beta_const, beta_start, beta_end;
     long long n_steps, n_chains, patience, hist_stride, bits_stride;
@@ -365,6 +382,21 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
 // ------------------------------------------------------------------------------------------------
 // sweep kernel
 // ------------------------------------------------------------------------------------------------
+// The SIMD's instruction arbiter serves the highest priority first and, among equals, the oldest wavefront.  Left alone,
+// the first wavefront of a SIMD runs almost unimpeded and the last one gets the leftovers: the four wavefronts of a SIMD
+// finish 16.6 / 21.3 / 26.8 / 32.6 ms into a 33 ms sweep, and the SIMD spends the second half of the kernel partly empty.
+// The sweep therefore paces itself: every 64 steps a wavefront compares its progress with that of the wavefronts sharing
+// its SIMD (a 16-word row per SIMD in the workspace) and sets its priority to the number of them that are ahead of it.
+// All 4 096 wavefronts of the headline run then finish within 5 % of each other (27.4 .. 28.7 ms).
+__device__ __forceinline__ void set_priority(int k) {  // s_setprio takes an immediate
+    switch (k) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // wave-uniform "some lane has p": the ballot is compared in the scalar unit (no per-lane 0/1 materialised)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
@@ -633,6 +665,11 @@ __global__ __launch_bounds__(256) void mcq_reduced_finalize_kernel(const unsigne
 // default kernels carry none of its code.
 template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED>
 __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
+    WAVE_T0;
+    // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
+    const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    const int wave_slot = (int)(hw_id & 15u);
+    uint32_t* pace_row = a.pace + 16u * (((xcc_id & 7u) << 8) | (((hw_id >> 13) & 3u) << 6) | (((hw_id >> 8) & 15u) << 2) | ((hw_id >> 4) & 3u));
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
     constexpr int WPL = 16 / G;
@@ -1109,6 +1146,14 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     n_acc += __popc(accw);  // accepted moves are counted from the bit words
                     if (bits && gl == 0) bits[step >> 5] = accw;
                     accw = 0;
+                    if ((step & 63) == 63) {
+                        // Pacing: publish this wavefront's progress, read the row of its SIMD, and take a priority that grows with
+                        // the number of co-resident wavefronts that are further along (ties fall to the arbiter's age order).
+                        const uint32_t mine = (uint32_t)step + 1u;
+                        if (lane == 0) __hip_atomic_store(pace_row + wave_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t other = lane < 16 ? __hip_atomic_load(pace_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        set_priority(min(3, (int)__popcll(__ballot(other > mine))));
+                    }
                 }
             }
         }
@@ -1120,6 +1165,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         }
     }
     STAMP_FLUSH(a.dbg);
+    WAVE_T1(a.dbg);
+    if (lane == 0) __hip_atomic_store(pace_row + wave_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a finished wavefront is ahead of nobody
     if (reduced && (last_entry & 15) != 15) reduce_block<G>(stage, gl, grp, last_entry & ~15, hist_len, red, a.red_len);  // partial last block
 
     if (active) {  // ran to n_steps: flush the partial last block and word
@@ -1214,7 +1261,7 @@ __global__ __launch_bounds__(256) void mcq_accept_bins_kernel(const unsigned lon
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512];
-#ifdef MCQ_STAMPS
+#if defined(MCQ_STAMPS) || defined(MCQ_WAVE_TIMES)
 unsigned long long* g_dbg = nullptr;
 #endif
 
@@ -1266,6 +1313,7 @@ size_t beta_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p
 size_t c32_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 4 + 255) & ~(size_t)255; }
 long long red_len_for(const mcq_params* p) { return (p->n_steps + 1 + 31) & ~31LL; }
 size_t red_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 4 * red_len_for(p) * 8 : 0; }
+constexpr size_t PACE_BYTES = 2048 * 16 * 4;  // 8 XCC x 4 SE x 16 CU x 4 SIMD rows of 16 wave slots
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
 // side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
@@ -1304,9 +1352,10 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->c32_tab = (float*)((char*)ws + beta_tab_bytes(p));
     a->red = p->trace == MCQ_TRACE_REDUCED ? (unsigned long long*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p)) : nullptr;
     a->red_len = red_len_for(p);
-    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p));
+    a->pace = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p));
+    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES);
     a->seeds = seeds, a->out = *out;
-#ifdef MCQ_STAMPS
+#if defined(MCQ_STAMPS) || defined(MCQ_WAVE_TIMES)
     a->dbg = g_dbg;
 #endif
     if (p->trace != MCQ_TRACE_I32) a->out.energy_hist = nullptr, a->out.accept_bits = nullptr;
@@ -1399,6 +1448,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         HIP_TRY(hipMemsetAsync(a.out.accept_bits, 0, (size_t)p->n_chains * p->bits_stride * 8, s));
 
     if (a.red) HIP_TRY(hipMemsetAsync(a.red, 0, red_bytes(p), s));
+    HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     if (p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM) init_lds += (size_t)p->N * p->N * p->N * 2;
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
@@ -1444,7 +1494,7 @@ size_t mcq_state_bytes(int32_t N, int32_t mode) {
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
-    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -1460,6 +1510,11 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 64));
     HIP_TRY(hipMemset(g_dbg, 0, 64));
 #endif
+#ifdef MCQ_WAVE_TIMES
+    const size_t wt_waves = 1 << 16;
+    if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, wt_waves * 32));
+    HIP_TRY(hipMemset(g_dbg, 0, wt_waves * 32));
+#endif
     int rc = run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, ev);
 #ifdef MCQ_STAMPS
     if (rc == MCQ_OK) {
@@ -1470,6 +1525,25 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
         unsigned long long tot = 0;
         for (int k = 0; k < 6; k++) tot += h[k];
         for (int k = 0; k < 6; k++) fprintf(stderr, "STAMP %-14s %14llu  %5.1f %%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
+    }
+#endif
+#ifdef MCQ_WAVE_TIMES
+    if (rc == MCQ_OK) {  // one line per wavefront: start and end in 10 ns ticks from the first start, XCC, SE, CU, SIMD
+        HIP_TRY(hipDeviceSynchronize());
+        unsigned long long* h = (unsigned long long*)malloc(wt_waves * 32);
+        HIP_TRY(hipMemcpy(h, g_dbg, wt_waves * 32, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < wt_waves; w++)
+            if (h[4 * w + 1] && h[4 * w] < t0) t0 = h[4 * w];
+        if (FILE* f = fopen(getenv("MCQ_WAVE_TIMES_OUT") ? getenv("MCQ_WAVE_TIMES_OUT") : "/tmp/mcq_wave_times.txt", "w")) {
+            for (size_t w = 0; w < wt_waves; w++)
+                if (h[4 * w + 1]) {
+                    const unsigned hw = (unsigned)h[4 * w + 3];
+                    fprintf(f, "%zu %llu %llu %u %u %u %u %u\n", w, h[4 * w] - t0, h[4 * w + 1] - t0, (unsigned)h[4 * w + 2], (hw >> 13) & 3, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15);
+                }
+            fclose(f);
+        }
+        free(h);
     }
 #endif
     float a = 0.f, b = 0.f;
