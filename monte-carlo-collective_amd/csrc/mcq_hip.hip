@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     n_acc += __popc(accw);  // accepted moves are counted from the bit words
                     if (bits && gl == 0) bits[step >> 5] = accw;
                     accw = 0;
-                    if ((step & 63) == 63) {
+                    if ((step & 63) == 63 && a.pace) {
                         // Pacing: publish this wavefront's progress, read the row of its SIMD, and take a priority that grows with
                         // the number of co-resident wavefronts that are further along (ties fall to the arbiter's age order).
                         const uint32_t mine = (uint32_t)step + 1u;
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     }
     STAMP_FLUSH(a.dbg);
     WAVE_T1(a.dbg);
-    if (lane == 0) __hip_atomic_store(pace_row + wave_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a finished wavefront is ahead of nobody
+    if (lane == 0 && a.pace) __hip_atomic_store(pace_row + wave_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a finished wavefront is ahead of nobody
     if (reduced && (last_entry & 15) != 15) reduce_block<G>(stage, gl, grp, last_entry & ~15, hist_len, red, a.red_len);  // partial last block
 
     if (active) {  // ran to n_steps: flush the partial last block and word
@@ -1362,9 +1362,21 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     return MCQ_OK;
 }
 
+// SIMDs of the current device (4 per compute unit)
+int device_simds() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1024;
+    return 4 * cus;
+}
+
 template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED>
-int launch_sweep(const KArgs& a, hipStream_t s) {
+int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
+    KArgs a = a0;
+    // Pacing pays when a SIMD holds several wavefronts of this launch (they can only see each other); a launch that puts less
+    // than two wavefronts on a SIMD would pay for the checkpoints and gain nothing.
+    const long long waves = (a.n_chains + CPB - 1) / CPB;
+    if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
