@@ -1,0 +1,56 @@
+"""Randomised differential test: parameter sets drawn from a fixed seed, HIP against the oracle through the C-ABI.
+Small runs (the oracle stays under a second each) over the whole parameter space: every N, both modes, the three
+initial states, the five schedules with ordinary and odd beta values, early stopping, all lane widths, the three trace
+modes' shared outputs, ragged chain counts and lengths around the flush boundaries (16 / 32 / 64 steps)."""
+import numpy as np
+import pytest
+
+import mcq_amd
+from mcq_amd import abi
+from oracle import oracle
+from tests import util
+
+N_CASES = 400
+
+
+def _cases():
+    rng = np.random.default_rng(20251004)
+    scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
+    out = []
+    for c in range(N_CASES):
+        mode = "board" if rng.random() < 0.55 else "full_3d"
+        N = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 23, 24, 25, 28, 32]))
+        if mode == "full_3d" and N > 20:
+            N = int(rng.integers(2, 21))  # the init permutation of N^3 cells keeps the oracle slow beyond that
+        init = str(rng.choice(["random", "latin", "klarner"]))
+        st = str(rng.choice(scheds))
+        if st == "constant":
+            sp = {"type": st, "beta_const": float(rng.choice([0.0, 0.3, 1.0, 2.5, 8.0, -0.5]))}
+        else:
+            lo = float(rng.choice([0.05, 0.5, 1.0, 2.0]))
+            hi = float(rng.choice([0.5, 2.0, 3.0, 6.0]))
+            if st == "exponential_annealing" and rng.random() < 0.2:
+                lo, hi = hi, lo  # cooling and heating
+            sp = {"type": st, "beta_start": lo, "beta_end": hi}
+        n_steps = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 257, 400]))
+        n_chains = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24]))
+        patience = None
+        if mode == "board" and rng.random() < 0.35:
+            patience = int(rng.choice([0, 1, 2, 10, 40, 1000]))
+        lanes = int(rng.choice([0, 4, 8, 16]))
+        seed0 = int(rng.integers(0, 2**32 - 1 - n_chains))
+        out.append((c, N, mode, init, sp, n_steps, n_chains, patience, lanes, seed0))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_random_parameter_sets():
+    for c, N, mode, init, sp, n_steps, n_chains, patience, lanes, seed0 in _cases():
+        what = f"case {c}: N={N} {mode} {init} {sp} n_steps={n_steps} n_chains={n_chains} patience={patience} lanes={lanes} seed0={seed0}"
+        p = abi.make_params(N, n_steps, init, sp, n_chains, mcmc_type=mode, early_stop_patience=patience, lanes_per_chain=lanes)
+        seeds = abi.seeds_for(seed0, n_chains)
+        want = oracle.run(p, seeds, n_threads=8)
+        got, _ = mcq_amd._lib.run_host(p, seeds)
+        util.assert_results_equal(got, want, what)
+        assert got["near_ties"].sum() == 0, what
