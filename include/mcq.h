@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCQ_ABI_VERSION 1
+#define MCQ_ABI_VERSION 2
 
 /* error codes */
 #define MCQ_OK 0
@@ -71,6 +71,15 @@ extern "C" {
 #define MCQ_MIN_N 2
 #define MCQ_MAX_N 32
 
+/* One beta schedule of a batched run (run_beta_start_end_pairs loops over such pairs: experiments.py:741-846). */
+typedef struct mcq_schedule {
+    int32_t sched;     /* MCQ_SCHED_* */
+    int32_t reserved;  /* 0 */
+    double beta_const;
+    double beta_start;
+    double beta_end;
+} mcq_schedule;
+
 typedef struct mcq_params {
     int32_t abi_version;     /* MCQ_ABI_VERSION */
     int32_t N;               /* board edge; Q = N*N queens */
@@ -90,6 +99,12 @@ typedef struct mcq_params {
     int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
     int32_t lanes_per_chain; /* HIP only: 4, 8 or 16 lanes of a wavefront per chain; 0 = library default */
     int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
+    /* Several schedules in ONE launch (everything else shared): n_sets <= 1 means the single schedule above.  Otherwise
+     * chains [t * chains_per_set, (t + 1) * chains_per_set) follow sets[t]; n_chains == n_sets * chains_per_set,
+     * chains_per_set is a multiple of 16, and with trace == REDUCED the step_* outputs are [n_sets][n_steps + 1]. */
+    int64_t n_sets;
+    int64_t chains_per_set;
+    const mcq_schedule* sets; /* HOST pointer (also for mcq_run_device), n_sets entries */
 } mcq_params;
 
 /*
@@ -111,7 +126,8 @@ typedef struct mcq_outputs {
     int64_t* near_ties;      /* optional [n_chains]: steps whose uniform fell within 4 ulp of the acceptance probability */
     uint8_t* best_state;     /* optional [n_chains][state_bytes] */
     uint8_t* final_state;    /* optional [n_chains][state_bytes] */
-    /* trace == REDUCED only, int64[n_steps + 1] each, indexed by history entry e (entry 0 = initial state): */
+    /* trace == REDUCED only, int64[n_steps + 1] each (per schedule set: [n_sets][n_steps + 1]), indexed by history entry e
+     * (entry 0 = initial state): */
     int64_t* step_sum;       /* sum over chains of energy_history[e]                                   */
     int64_t* step_sumsq;     /* sum of squares                                                         */
     int64_t* step_accepted;  /* chains whose step e - 1 was accepted (entry 0: 0)                       */

@@ -106,7 +106,7 @@ def run_host(params, seeds, trace=True, states=True):
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
     if seeds.shape != (params.n_chains,):
         raise ValueError("seeds must have one entry per chain")
-    p = abi.Params.from_buffer_copy(params)
+    p = abi.copy_params(params)
     p.trace = abi.trace_mode(trace)
     arrays = {k: np.zeros(shape, dtype=abi.OUTPUT_DTYPES[k])
               for k, shape in abi.output_shapes(p, trace=trace, states=states).items()}
@@ -129,7 +129,7 @@ class DeviceRun:
 
         self.torch = torch
         self.L = lib()
-        self.p = abi.Params.from_buffer_copy(params)
+        self.p = abi.copy_params(params)
         self.p.trace = abi.trace_mode(trace)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         tdt = {np.int32: torch.int32, np.int64: torch.int64, np.uint8: torch.uint8, np.uint64: torch.int64}

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, EINVAL, EDEVICE, ENOMEM = 0, -1, -2, -3
 
@@ -27,6 +27,17 @@ FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
 
 MIN_N, MAX_N = 2, 32
+
+
+class Schedule(C.Structure):
+    """include/mcq.h: mcq_schedule -- one beta schedule of a batched run"""
+    _fields_ = [
+        ("sched", C.c_int32),
+        ("reserved", C.c_int32),
+        ("beta_const", C.c_double),
+        ("beta_start", C.c_double),
+        ("beta_end", C.c_double),
+    ]
 
 
 class Params(C.Structure):
@@ -49,6 +60,9 @@ class Params(C.Structure):
         ("bits_stride", C.c_int64),
         ("lanes_per_chain", C.c_int32),
         ("device", C.c_int32),
+        ("n_sets", C.c_int64),
+        ("chains_per_set", C.c_int64),
+        ("sets", C.POINTER(Schedule)),
     ]
 
 
@@ -116,7 +130,7 @@ def output_shapes(p, trace=True, states=True):
                                 "steps_to_best", "n_accepted", "near_ties")}
     if isinstance(trace, str) and trace == "reduced":
         for k in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
-            shapes[k] = (p.n_steps + 1,)
+            shapes[k] = (p.n_sets, p.n_steps + 1) if p.n_sets > 1 else (p.n_steps + 1,)
     elif trace:
         shapes["energy_hist"] = (n, p.hist_stride)
         shapes["accept_bits"] = (n, p.bits_stride)
@@ -145,6 +159,46 @@ def normalise_patience(early_stop_patience):
         return -1
     v = int(early_stop_patience)
     return v if v >= 0 else 0  # a negative patience stops at the first step, like 0
+
+
+def _check_schedule(schedule_params):
+    """(type, beta_const, beta_start, beta_end) of a betta_scheduling dict; raises like the reference (experiments.py:85-105)"""
+    if schedule_params is None:
+        raise ValueError("schedule_params is required")
+    st = schedule_params.get("type")
+    if st not in SCHED:
+        raise ValueError(f"Unknown betta_scheduling type: {st}")
+    bc = schedule_params.get("beta_const")
+    bs = schedule_params.get("beta_start")
+    be = schedule_params.get("beta_end")
+    if st == "constant":
+        if bc is None:
+            raise ValueError("beta_const required for constant schedule")
+    elif bs is None or be is None:
+        raise ValueError(f"beta_start and beta_end required for {st} schedule")
+    f = lambda v: float(v) if v is not None else 0.0
+    return st, f(bc), f(bs), f(be)
+
+
+def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_type="full_3d", early_stop_patience=None,
+                     trace=True, flags=0, lanes_per_chain=0, device=-1):
+    """Parameters of ONE launch that runs `chains_per_set` chains under each schedule of `schedule_sets` (a list of
+    betta_scheduling dicts): chains [t * chains_per_set, (t + 1) * chains_per_set) follow schedule t.  What
+    run_beta_start_end_pairs does pair by pair (experiments.py:741-846), batched."""
+    sets = [_check_schedule(sp) for sp in schedule_sets]
+    if not sets:
+        raise ValueError("at least one schedule")
+    if chains_per_set <= 0 or chains_per_set % 16:
+        raise ValueError("chains_per_set must be a positive multiple of 16")
+    p = make_params(N, n_steps, init_mode, schedule_sets[0], chains_per_set * len(sets), mcmc_type=mcmc_type,
+                    early_stop_patience=early_stop_patience, trace=trace, flags=flags, lanes_per_chain=lanes_per_chain, device=device)
+    arr = (Schedule * len(sets))()
+    for a, (st, bc, bs, be) in zip(arr, sets):
+        a.sched, a.reserved, a.beta_const, a.beta_start, a.beta_end = SCHED[st], 0, bc, bs, be
+    p.n_sets, p.chains_per_set = len(sets), chains_per_set
+    p.sets = C.cast(arr, C.POINTER(Schedule))
+    p._sets_keepalive = arr  # the struct only holds a pointer
+    return p
 
 
 def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="full_3d", early_stop_patience=None,
@@ -202,3 +256,12 @@ def seeds_for(base_seed, n_chains):
     if n_chains and (s[0] < 0 or s[-1] > 2**32 - 1):
         raise ValueError("Seed must be between 0 and 2**32 - 1")
     return s.astype(np.uint32)
+
+
+def copy_params(params):
+    """A private copy of a Params block (the schedule-set array it may point to is kept alive with the copy)."""
+    p = Params.from_buffer_copy(params)
+    keep = getattr(params, "_sets_keepalive", None)
+    if keep is not None:
+        p._sets_keepalive = keep
+    return p

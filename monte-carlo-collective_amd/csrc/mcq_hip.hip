@@ -109,6 +109,9 @@ struct KArgs {
     int state_bytes;
     int rec_words;          // words per chain record in the workspace
     int chain_lds_words;    // words of LDS per chain in the sweep kernel
+    long long chains_per_set;  // schedule sets: chains per set (0: one set)
+    long long tab_stride;      // schedule sets: elements between the tables of consecutive sets (beta_tab and c32_tab alike)
+    long long red_set_stride;  // schedule sets, trace == REDUCED: accumulator words per set
     uint32_t* pace;         // progress table: one row of 16 words per SIMD of the device, word = step reached by the wavefront in that slot
     int full_pad;           // full_3d: spare column words on either side of the column table (>= N-1: out-of-board diagonal probes)
     double beta_const, beta_start, beta_end;
@@ -723,7 +726,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
     int hist_len = active ? (int)a.n_steps + 1 : 0;
-    unsigned long long* red = reduced ? a.red + (long long)(blockIdx.x & (RED_STRIPES - 1)) * 4 * a.red_len : nullptr;
+    unsigned long long* red = reduced ? a.red + (a.chains_per_set > 0 ? ((long long)blockIdx.x * CPW) / a.chains_per_set : 0) * a.red_set_stride +
+                                            (long long)(blockIdx.x & (RED_STRIPES - 1)) * 4 * a.red_len
+                                      : nullptr;
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
@@ -745,8 +750,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     // lets the compiler fetch them with scalar loads (one s_load per step instead of a vector load)
     typedef const __attribute__((address_space(4))) float* const_f32_ptr;
     typedef const __attribute__((address_space(4))) double* const_f64_ptr;
-    const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)a.c32_tab;
-    const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)a.beta_tab;
+    // schedule sets: every chain of a wavefront belongs to the same set (chains_per_set is a multiple of 16)
+    const long long set_idx = a.chains_per_set > 0 ? ((long long)blockIdx.x * CPW) / a.chains_per_set : 0;
+    const const_f32_ptr c32_tab = (const_f32_ptr)(unsigned long long)(a.c32_tab + set_idx * a.tab_stride);
+    const const_f64_ptr beta_tab = (const_f64_ptr)(unsigned long long)(a.beta_tab + set_idx * a.tab_stride);
 
     // Packed dE probes (N <= 16 <=> NT <= 4): lane constants of the NT columns / rows this lane probes.  Board: the G
     // lanes of a chain share the 4N probes; full_3d: half of the lanes probe around the new cell, the other half around the old.
@@ -1303,16 +1310,28 @@ int validate(const mcq_params* p) {
     if (p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_chains");
     if (p->lanes_per_chain != 0 && p->lanes_per_chain != 4 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
         return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 4, 8 or 16");
+    if (p->n_sets < 0) return fail(MCQ_EINVAL, "negative n_sets");
+    if (p->n_sets > 1) {
+        if (!p->sets) return fail(MCQ_EINVAL, "n_sets > 1 without sets");
+        if (p->chains_per_set <= 0 || p->chains_per_set % 16 != 0) return fail(MCQ_EINVAL, "chains_per_set must be a positive multiple of 16");
+        if (p->n_chains != p->n_sets * p->chains_per_set) return fail(MCQ_EINVAL, "n_chains must equal n_sets * chains_per_set");
+        for (int64_t t = 0; t < p->n_sets; t++)
+            if (p->sets[t].sched < MCQ_SCHED_CONSTANT || p->sets[t].sched > MCQ_SCHED_SINUSOIDAL) return fail(MCQ_EINVAL, "unknown schedule type in sets");
+    }
     return MCQ_OK;
 }
 
 // 64-byte multiple: the sweep reads and writes the MT words of a record in aligned 64-byte blocks
 int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 15) & ~15; }
 
-size_t beta_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 8 + 255) & ~(size_t)255; }
-size_t c32_tab_bytes(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) * 4 + 255) & ~(size_t)255; }
+size_t n_sets_of(const mcq_params* p) { return p->n_sets > 1 ? (size_t)p->n_sets : 1; }
+// one table per schedule set, tab_stride elements apart (a 256-byte multiple for either element size)
+size_t tab_stride_for(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) + 63) & ~(size_t)63; }
+size_t beta_tab_bytes(const mcq_params* p) { return n_sets_of(p) * tab_stride_for(p) * 8; }
+size_t c32_tab_bytes(const mcq_params* p) { return n_sets_of(p) * tab_stride_for(p) * 4; }
 long long red_len_for(const mcq_params* p) { return (p->n_steps + 1 + 31) & ~31LL; }
-size_t red_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 4 * red_len_for(p) * 8 : 0; }
+size_t red_set_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 4 * red_len_for(p) * 8 : 0; }
+size_t red_bytes(const mcq_params* p) { return n_sets_of(p) * red_set_bytes(p); }
 constexpr size_t PACE_BYTES = 2048 * 16 * 4;  // 8 XCC x 4 SE x 16 CU x 4 SIMD rows of 16 wave slots
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
@@ -1352,6 +1371,9 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->c32_tab = (float*)((char*)ws + beta_tab_bytes(p));
     a->red = p->trace == MCQ_TRACE_REDUCED ? (unsigned long long*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p)) : nullptr;
     a->red_len = red_len_for(p);
+    a->chains_per_set = p->n_sets > 1 ? p->chains_per_set : 0;
+    a->tab_stride = (long long)tab_stride_for(p);
+    a->red_set_stride = (long long)(red_set_bytes(p) / 8);
     a->pace = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p));
     a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES);
     a->seeds = seeds, a->out = *out;
@@ -1447,7 +1469,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (p->n_chains == 0) {
         if (p->trace == MCQ_TRACE_REDUCED)
             for (int64_t* arr : {out->step_sum, out->step_sumsq, out->step_accepted, out->step_count})
-                HIP_TRY(hipMemsetAsync(arr, 0, (size_t)(p->n_steps + 1) * 8, s));
+                HIP_TRY(hipMemsetAsync(arr, 0, n_sets_of(p) * (size_t)(p->n_steps + 1) * 8, s));
         if (ev)
             for (int t = 0; t < 3; t++) HIP_TRY(hipEventRecord(ev[t], s));
         return MCQ_OK;
@@ -1465,7 +1487,14 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM) init_lds += (size_t)p->N * p->N * p->N * 2;
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    if (p->n_steps > 0) hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, a);
+    if (p->n_steps > 0) {
+        for (size_t t = 0; t < n_sets_of(p); t++) {  // one table pair per schedule set
+            KArgs b = a;
+            if (p->n_sets > 1) b.sched = p->sets[t].sched, b.beta_const = p->sets[t].beta_const, b.beta_start = p->sets[t].beta_start, b.beta_end = p->sets[t].beta_end;
+            b.beta_tab = a.beta_tab + t * a.tab_stride, b.c32_tab = a.c32_tab + t * a.tab_stride;
+            hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, b);
+        }
+    }
     hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
@@ -1475,8 +1504,10 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (rc != MCQ_OK) return rc;
     if (a.red) {
         const long long n_entries = p->n_steps + 1;
-        hipLaunchKernelGGL(mcq_reduced_finalize_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s, a.red, a.red_len, n_entries,
-                           (long long*)out->step_sum, (long long*)out->step_sumsq, (long long*)out->step_accepted, (long long*)out->step_count);
+        for (size_t t = 0; t < n_sets_of(p); t++)
+            hipLaunchKernelGGL(mcq_reduced_finalize_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s, a.red + t * a.red_set_stride,
+                               a.red_len, n_entries, (long long*)out->step_sum + t * n_entries, (long long*)out->step_sumsq + t * n_entries,
+                               (long long*)out->step_accepted + t * n_entries, (long long*)out->step_count + t * n_entries);
         HIP_TRY(hipGetLastError());
     }
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
@@ -1633,10 +1664,10 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
         {(void**)&d.near_ties, out->near_ties, n * 8},
         {(void**)&d.best_state, out->best_state, n * sb},
         {(void**)&d.final_state, out->final_state, n * sb},
-        {(void**)&d.step_sum, p->trace == MCQ_TRACE_REDUCED ? out->step_sum : nullptr, (size_t)(p->n_steps + 1) * 8},
-        {(void**)&d.step_sumsq, p->trace == MCQ_TRACE_REDUCED ? out->step_sumsq : nullptr, (size_t)(p->n_steps + 1) * 8},
-        {(void**)&d.step_accepted, p->trace == MCQ_TRACE_REDUCED ? out->step_accepted : nullptr, (size_t)(p->n_steps + 1) * 8},
-        {(void**)&d.step_count, p->trace == MCQ_TRACE_REDUCED ? out->step_count : nullptr, (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_sum, p->trace == MCQ_TRACE_REDUCED ? out->step_sum : nullptr, n_sets_of(p) * (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_sumsq, p->trace == MCQ_TRACE_REDUCED ? out->step_sumsq : nullptr, n_sets_of(p) * (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_accepted, p->trace == MCQ_TRACE_REDUCED ? out->step_accepted : nullptr, n_sets_of(p) * (size_t)(p->n_steps + 1) * 8},
+        {(void**)&d.step_count, p->trace == MCQ_TRACE_REDUCED ? out->step_count : nullptr, n_sets_of(p) * (size_t)(p->n_steps + 1) * 8},
     };
     uint32_t* d_seeds = nullptr;
     void* d_ws = nullptr;

@@ -531,6 +531,14 @@ typedef struct {
 } pool_t;
 
 static int run_one(const job_t* jb, int64_t r) {
+    if (jb->p->n_sets > 1) { /* batched schedules: chain r follows sets[r / chains_per_set] */
+        const mcq_schedule* sc = &jb->p->sets[r / jb->p->chains_per_set];
+        mcq_params q = *jb->p;
+        job_t one = *jb;
+        q.sched = sc->sched, q.beta_const = sc->beta_const, q.beta_start = sc->beta_start, q.beta_end = sc->beta_end;
+        one.p = &q;
+        return q.mode == MCQ_MODE_BOARD ? run_board_chain(&one, r) : run_full_chain(&one, r);
+    }
     return jb->p->mode == MCQ_MODE_BOARD ? run_board_chain(jb, r) : run_full_chain(jb, r);
 }
 
@@ -559,6 +567,13 @@ int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL)
         return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
+    if (p->n_sets > 1) {
+        if (!p->sets || p->chains_per_set <= 0 || p->n_chains != p->n_sets * p->chains_per_set)
+            return fail(MCQ_EINVAL, "bad schedule sets");
+        for (int64_t t = 0; t < p->n_sets; t++)
+            if (p->sets[t].sched < MCQ_SCHED_CONSTANT || p->sets[t].sched > MCQ_SCHED_SINUSOIDAL)
+                return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
+    }
     if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "unknown rng");
     if (p->n_steps < 0 || p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_steps / n_chains");
     if (out->energy_hist && p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");

@@ -54,7 +54,7 @@ def run(params, seeds, trace=True, states=True, n_threads=1):
     out = abi.Outputs()
     for k, a in arrays.items():
         setattr(out, k, a.ctypes.data)
-    p = abi.Params.from_buffer_copy(params)
+    p = abi.copy_params(params)
     p.trace = abi.trace_mode(trace)
     rc = lib().mcq_oracle_run(C.byref(p), seeds.ctypes.data, C.byref(out), int(n_threads))
     if rc != 0:

@@ -69,6 +69,32 @@ def main():
         run_set(f"C5 beta_start_end_pairs N=24 board sinusoidal, 16 pairs x {a.chains} chains",
                 [dict(N=24, n_steps=n, init="random", sp={"type": "sinusoidal_annealing", "beta_start": s, "beta_end": e},
                       n_chains=a.chains, mode="board", seed=42 + 1000 * i) for i, (s, e) in enumerate(pairs)], trace=True)
+    if a.only in ("", "c5", "c5b"):
+        # the same 16 pairs as ONE launch with 16 schedule sets (mcq_params.sets)
+        import numpy as np
+        import torch
+
+        import mcq_amd
+
+        abi = mcq_amd.abi
+        pairs = [(s, e) for s in (0.1, 0.5, 1.0, 2.0) for e in (2.0, 3.0, 5.0, 8.0)]
+        sets = [{"type": "sinusoidal_annealing", "beta_start": s, "beta_end": e} for s, e in pairs]
+        p = abi.make_params_sets(24, n, "random", sets, a.chains, mcmc_type="board", trace=True)
+        seeds = np.concatenate([abi.seeds_for(42 + 1000 * i, a.chains) for i in range(len(pairs))])
+        run = mcq_amd._lib.DeviceRun(p, seeds, trace=True, states=False)
+        run.launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run.launch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        moves = int(run.t["steps_executed"].sum().item())
+        best = run.t["best_energy"].reshape(len(pairs), a.chains).min(dim=1).values.tolist()
+        print(json.dumps({"config": f"C5 batched: the 16 pairs x {a.chains} chains as one launch with 16 schedule sets", "launches": 1,
+                          "chains": len(seeds), "moves": moves, "seconds": dt, "moves_per_s": moves / dt, "min_energy_per_launch": best,
+                          "trace": "i32"}), flush=True)
+        del run
+        torch.cuda.empty_cache()
     if a.only in ("", "c4"):
         jobs = []
         for init in ("random", "latin", "klarner"):
