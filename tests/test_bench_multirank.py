@@ -37,6 +37,13 @@ def test_two_ranks_equal_one_rank():
     for k in ("min_energy", "mean_best_energy", "acceptance_rate"):  # same 8192 chains, same seeds, however they are split
         assert two[k] == one[k], k
     assert two["scaling"] == "weak" and two["unit"] == "moves/s" and two["value"] > 0
+    # the bench contract: every key the driver reads, on both lines
+    for line in (one, two):
+        for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline"):
+            assert k in line, k
+        assert line["higher_is_better"] is True and line["vs_baseline"] is None and "workload" in line["config"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"]) and line["roofline"]["bound"] == "hbm"
 
 
 @pytest.mark.gpu
