@@ -213,8 +213,10 @@ def run_many(params_list, seeds_list, trace=True, states=False):
     streams = [torch.cuda.Stream() for _ in runs]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for r, st in zip(runs, streams):
-        r.launch(stream=st)
+    # longest first (a step costs roughly N lane-operations per chain): the short sets then fill the end of the long ones
+    order = sorted(range(len(runs)), key=lambda i: -(runs[i].p.N * runs[i].p.n_steps * runs[i].p.n_chains))
+    for i in order:
+        runs[i].launch(stream=streams[i])
     for st in streams:
         st.synchronize()
     secs = time.perf_counter() - t0

@@ -30,8 +30,9 @@ def run_set(name, jobs, trace):
         r.launch(stream=st)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for r, st in zip(runs, streams):
-        r.launch(stream=st)
+    order = sorted(range(len(runs)), key=lambda i: -(runs[i].p.N * runs[i].p.n_steps * runs[i].p.n_chains))  # longest first, as _lib.run_many
+    for i in order:
+        runs[i].launch(stream=streams[i])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     moves = sum(int(r.t["steps_executed"].sum().item()) for r in runs)
