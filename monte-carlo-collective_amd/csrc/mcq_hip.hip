@@ -636,7 +636,20 @@ __device__ __forceinline__ void reduce_block(const uint32_t* stage, int gl, int 
         uint32_t se = valid ? x & 0x7fffffffu : 0u;                       // sum of E
         unsigned long long sq = (unsigned long long)se * se;              // sum of E^2
         uint32_t ac = valid ? (x >> 31) | 0x10000u : 0u;                  // accepted count | chains << 16
-        for (int off = G; off < 64; off <<= 1) {                          // over the 64 / G chains of the wavefront
+        // over the 64 / G chains of the wavefront: inside a row of 16 lanes with DPP rotations (full rate, no LDS traffic),
+        // across the four rows with two butterfly steps
+        uint32_t sl = (uint32_t)sq, sh = (uint32_t)(sq >> 32);
+        auto ror_add = [](uint32_t v, auto ctrl) { return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
+        auto ror_add64 = [](uint32_t& lo, uint32_t& hi, auto ctrl) {
+            const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, decltype(ctrl)::value, 0xf, 0xf, false);
+            const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, decltype(ctrl)::value, 0xf, 0xf, false);
+            const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)h2 << 32) | l2);
+            lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+        };
+        if (G <= 4) se = ror_add(se, std::integral_constant<int, 0x124>()), ac = ror_add(ac, std::integral_constant<int, 0x124>()), ror_add64(sl, sh, std::integral_constant<int, 0x124>());  // row_ror:4
+        if (G <= 8) se = ror_add(se, std::integral_constant<int, 0x128>()), ac = ror_add(ac, std::integral_constant<int, 0x128>()), ror_add64(sl, sh, std::integral_constant<int, 0x128>());  // row_ror:8
+        sq = ((unsigned long long)sh << 32) | sl;
+        for (int off = 16; off < 64; off <<= 1) {
             se += (uint32_t)__shfl_xor((int)se, off, 64);
             ac += (uint32_t)__shfl_xor((int)ac, off, 64);
             sq += ((unsigned long long)(uint32_t)__shfl_xor((int)(sq >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sq, off, 64);
