@@ -168,7 +168,7 @@ def main():
                         f"{sp.get('beta_start', sp.get('beta_const'))}->{sp.get('beta_end', '')} "
                         f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace else 'none'}",
             "chains_total": total_chains,
-            "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes(run.p.mode)),
+            "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes_n(run.p.mode, run.p.N)),
             "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summary all-reduce (MIN/SUM)",
         },
         "min_energy": min_energy,

@@ -140,8 +140,10 @@ int mcq_abi_version(void);
 const char* mcq_last_error(void);
 int mcq_device_count(void);
 
-/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0 (board: 4, full_3d: 8) */
+/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 16 and 8 beyond, full_3d 8
+ * (mcq_default_lanes: the value for N <= 16) */
 int32_t mcq_default_lanes(int32_t mode);
+int32_t mcq_default_lanes_n(int32_t mode, int32_t N);
 
 /* bytes of one chain's state record in best_state / final_state; 0 on bad arguments */
 size_t mcq_state_bytes(int32_t N, int32_t mode);

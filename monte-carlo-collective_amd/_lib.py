@@ -65,6 +65,8 @@ def lib():
         L.mcq_device_count.restype = C.c_int
         L.mcq_default_lanes.restype = C.c_int32
         L.mcq_default_lanes.argtypes = [C.c_int32]
+        L.mcq_default_lanes_n.restype = C.c_int32
+        L.mcq_default_lanes_n.argtypes = [C.c_int32, C.c_int32]
         L.mcq_state_bytes.restype = C.c_size_t
         L.mcq_state_bytes.argtypes = [C.c_int32, C.c_int32]
         L.mcq_workspace_bytes.restype = C.c_size_t

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     //   krc     selector of the row / column probe (board: one bit per half; full_3d: everything)
     //   vdm     bit (j - i + 16) set iff the diagonal probe (m, m - i + j) is on the board
     //   vam     bit (i + j) set iff the anti-diagonal probe (m, i + j - m) is
-    constexpr bool PACKED = (MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 4) || NARROW;  // N <= 16
+    constexpr bool PACKED = (MODE == MCQ_MODE_BOARD && NT >= 1 && NT * G <= 16) || NARROW;  // N <= 16
     constexpr int PG = NARROW ? G / 2 : G;  // lanes that share one set of probes
     constexpr int NTP = PACKED ? NT : 1;
     int pm[NTP];
@@ -789,6 +789,15 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         vdm[t] = inb && PACKED ? full << ((16 - pm[t]) & 31) : 0u;
         vam[t] = inb && PACKED ? full << (pm[t] & 31) : 0u;
     }
+
+    // Stream upkeep cadence.  A block of 16 words per two steps feeds 8 words per step; a board step uses
+    // 3 (mask + 1) / N + 2 words on average (three masked-rejection draws and the uniform): 6.1 at N = 12, but 7.3 .. 7.7 at
+    // N = 9, 17, 18, 19, where the mask accepts little more than half of the words.  Those sizes, like full_3d (8.1 words per
+    // step), run the upkeep on every step; a block then lands one step after it was requested, so it is requested earlier.
+    const bool every_step = MODE == MCQ_MODE_FULL3D || 3u * (maskN + 1u) > 5u * (unsigned)N;
+    // a block needs gen - pos <= 48 when it lands: requested at <= 58 two board steps (>= 10 words) earlier, or one step earlier at
+    // <= 53 (board, >= 5 words per step) / <= 54 (full_3d, >= 6)
+    const uint32_t room_limit = !every_step ? 58u : MODE == MCQ_MODE_BOARD ? 53u : 54u;
 
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 if (rng.pending) rng.complete();
                 // the block lands at the next upkeep, after >= 10 (board: two steps) or >= 6 (full_3d) more
                 // words were consumed, or earlier only if the ring ran dry: there is room for its 16 words
-                if (rng.gen - rng.pos <= (MODE == MCQ_MODE_BOARD ? 58u : 54u)) rng.issue();
+                if (rng.gen - rng.pos <= room_limit) rng.issue();
                 STAMP(1);  // stream upkeep: complete + issue
             };
             // sequential draws: one word at a time from what the ring holds, topping it up when it runs dry
@@ -880,7 +889,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             };
 
-            const bool upkeep_now = MODE == MCQ_MODE_FULL3D || (step & 1) == 0;
+            const bool upkeep_now = every_step || (step & 1) == 0;
             bool batched;  // the batched draw below succeeded for this chain
             if constexpr (MODE == MCQ_MODE_BOARD) {
                 // Straight-line for every chain of the wavefront (no divergent branch): positions of the next four
@@ -1453,6 +1462,9 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 default: break;
                 }
         }
+        if constexpr (G == 8) {  // larger boards run 8 lanes per chain by default: 3 or 4 straight-line probe passes
+            if (!pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
+        }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     }
@@ -1512,7 +1524,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
 
-    const int G = p->lanes_per_chain ? p->lanes_per_chain : mcq_default_lanes(p->mode);
+    const int G = p->lanes_per_chain ? p->lanes_per_chain : mcq_default_lanes_n(p->mode, p->N);
     rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
     if (a.red) {
@@ -1542,6 +1554,9 @@ int mcq_device_count(void) {
 }
 
 int32_t mcq_default_lanes(int32_t mode) { return mode == MCQ_MODE_BOARD ? 4 : 8; }
+
+// board: 4 lanes up to N = 16 and 8 beyond (measured at N = 24: 56 ms against 73 ms per 20 000 steps of 65 536 chains); full_3d: 8
+int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_BOARD && N > 16 ? 8 : mcq_default_lanes(mode); }
 
 size_t mcq_state_bytes(int32_t N, int32_t mode) {
     if (N < MCQ_MIN_N || N > MCQ_MAX_N) return 0;
