@@ -140,8 +140,8 @@ int mcq_abi_version(void);
 const char* mcq_last_error(void);
 int mcq_device_count(void);
 
-/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 16 and 8 beyond, full_3d 8
- * (mcq_default_lanes: the value for N <= 16) */
+/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 12 and 8 beyond, full_3d 8
+ * (mcq_default_lanes: the value for small boards) */
 int32_t mcq_default_lanes(int32_t mode);
 int32_t mcq_default_lanes_n(int32_t mode, int32_t N);
 

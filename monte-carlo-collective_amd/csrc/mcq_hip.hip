@@ -1464,6 +1464,7 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         }
         if constexpr (G == 8) {  // larger boards run 8 lanes per chain by default: 3 or 4 straight-line probe passes
             if (!pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
+            if (!pat && !a.red && a.N > 8) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
         }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
@@ -1555,8 +1556,9 @@ int mcq_device_count(void) {
 
 int32_t mcq_default_lanes(int32_t mode) { return mode == MCQ_MODE_BOARD ? 4 : 8; }
 
-// board: 4 lanes up to N = 16 and 8 beyond (measured at N = 24: 56 ms against 73 ms per 20 000 steps of 65 536 chains); full_3d: 8
-int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_BOARD && N > 16 ? 8 : mcq_default_lanes(mode); }
+// board: 4 lanes up to N = 12, where 16 chains per wavefront still fit 16 wavefronts per CU (<= 640 B of LDS per chain), and 8
+// beyond (65 536 chains x 20 000 steps: N = 13 42 ms against 49 ms, N = 16 42 / 52, N = 20 56 / 70, N = 24 56 / 73); full_3d: 8
+int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_BOARD && N > 12 ? 8 : mcq_default_lanes(mode); }
 
 size_t mcq_state_bytes(int32_t N, int32_t mode) {
     if (N < MCQ_MIN_N || N > MCQ_MAX_N) return 0;
