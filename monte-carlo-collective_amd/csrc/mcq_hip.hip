@@ -359,18 +359,46 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
         }
     }
 
-    // E0 = number of unordered attacking pairs (mcmc_board.py:82-122, mcmc.py:134-169)
+    // E0 = number of unordered attacking pairs (mcmc_board.py:82-122, mcmc.py:134-169).  Two distinct cells attack iff they
+    // share one of the 13 lines through a cell, and no two cells share more than one, so E0 = sum over lines of c (c - 1) / 2
+    // with c the queens on the line: one byte counter per line (c <= N <= 32), O(Q) increments instead of Q^2 / 2 pair tests.
+    //   N^2 lines each:        (j, k) along i | (i, k) along j | (i, j) along k
+    //   N (2N - 1) lines each: (k, i - j), (k, i + j) | (j, i - k), (j, i + k) | (i, j - k), (i, j + k)      planar diagonals
+    //   (2N - 1)^2 lines each: (i - j, i - k), (i - j, i + k), (i + j, i - k), (i + j, i + k)                space diagonals
+    // The counters take the place of the permutation array (no longer needed).
     int e = 0;
-    for (int p = lane; p < Q * Q; p += 64) {
-        const int x = p / Q, y = p % Q;
-        if (x < y) {
-            int xi, xj, xk, yi, yj, yk;
-            if (a.mode == MCQ_MODE_BOARD) {
-                xi = x / N, xj = x % N, xk = st[x], yi = y / N, yj = y % N, yk = st[y];
-            } else {
-                xi = st[3 * x], xj = st[3 * x + 1], xk = st[3 * x + 2], yi = st[3 * y], yj = st[3 * y + 1], yk = st[3 * y + 2];
+    {
+        uint32_t* cnt = (uint32_t*)perm;
+        const int D = 2 * N - 1, n_lines = 3 * Q + 6 * N * D + 4 * D * D;
+        for (int w = lane; w < (n_lines + 3) / 4; w += 64) cnt[w] = 0;
+        auto bump = [&](int line) { atomicAdd(&cnt[line >> 2], 1u << (8 * (line & 3))); };
+        for (int c = lane; c < Q; c += 64) {
+            int i, j, k;
+            if (a.mode == MCQ_MODE_BOARD) i = c / N, j = c % N, k = st[c];
+            else i = st[3 * c], j = st[3 * c + 1], k = st[3 * c + 2];
+            const int dij = i - j + N - 1, dik = i - k + N - 1, djk = j - k + N - 1, sij = i + j, sik = i + k, sjk = j + k;
+            int base = 0;
+            bump(base + j * N + k), base += Q;
+            bump(base + i * N + k), base += Q;
+            bump(base + i * N + j), base += Q;
+            bump(base + k * D + dij), base += N * D;
+            bump(base + k * D + sij), base += N * D;
+            bump(base + j * D + dik), base += N * D;
+            bump(base + j * D + sik), base += N * D;
+            bump(base + i * D + djk), base += N * D;
+            bump(base + i * D + sjk), base += N * D;
+            bump(base + dij * D + dik), base += D * D;
+            bump(base + dij * D + sik), base += D * D;
+            bump(base + sij * D + dik), base += D * D;
+            bump(base + sij * D + sik);
+        }
+        for (int w = lane; w < (n_lines + 3) / 4; w += 64) {
+            const uint32_t x = cnt[w];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = (int)((x >> (8 * b)) & 0xffu);
+                e += c * (c - 1) / 2;
             }
-            e += on_a_line(xi - yi, xj - yj, xk - yk) ? 1 : 0;
         }
     }
     e = wave_sum(e);
@@ -1510,7 +1538,11 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (a.red) HIP_TRY(hipMemsetAsync(a.red, 0, red_bytes(p), s));
     HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
-    if (p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM) init_lds += (size_t)p->N * p->N * p->N * 2;
+    {  // behind the state: the permutation array of np.random.choice (full_3d random init), then the E0 line counters
+        const size_t D = 2 * (size_t)p->N - 1, lines = ((3 * (size_t)a.Q + 6 * p->N * D + 4 * D * D + 3) / 4) * 4;
+        const size_t perm = p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM ? (size_t)p->N * p->N * p->N * 2 : 0;
+        init_lds += perm > lines ? perm : lines;
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     if (p->n_steps > 0) {
