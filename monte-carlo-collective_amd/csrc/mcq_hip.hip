@@ -1478,6 +1478,14 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
     } else {
         const bool pat = a.patience >= 0;
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
+            // (early stopping -- the reference's default early_stop_patience = 100000 -- has its own unrolled variants for the
+            // sizes that default to 4 lanes)
+            if (pat && !a.red) switch ((a.N + G - 1) / G) {
+                case 1: return launch_sweep<MODE, G, true, 1, false>(a, s);
+                case 2: return launch_sweep<MODE, G, true, 2, false>(a, s);
+                case 3: return launch_sweep<MODE, G, true, 3, false>(a, s);
+                default: break;
+                }
             if (!pat) switch ((a.N + G - 1) / G) {
 #define MCQ_NT_CASE(nt) case nt: return a.red ? launch_sweep<MODE, G, false, (nt == 4 ? 0 : nt), true>(a, s) : launch_sweep<MODE, G, false, nt, false>(a, s)
                 MCQ_NT_CASE(1);  // N = 2..4
@@ -1493,6 +1501,8 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         if constexpr (G == 8) {  // larger boards run 8 lanes per chain by default: 3 or 4 straight-line probe passes
             if (!pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
             if (!pat && !a.red && a.N > 8) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
+            if (pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, true, 3, false>(a, s) : launch_sweep<MODE, G, true, 4, false>(a, s);
+            if (pat && !a.red && a.N > 8) return launch_sweep<MODE, G, true, 2, false>(a, s);
         }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
