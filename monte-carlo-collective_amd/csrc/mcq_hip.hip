@@ -471,7 +471,7 @@ __device__ __forceinline__ uint32_t group_or(uint32_t u) {
 //
 // The 624 raw MT19937 words of a chain stay in its record in GLOBAL memory (2.5 KB per chain would
 // cap a CU at ~56 chains if they lived in LDS).  They are regenerated in blocks of 16 words, 16/G
-// words per lane: the block's inputs are loaded (`issue`) two Metropolis steps before they are
+// words per lane: the block's inputs are loaded (`issue`) one or more Metropolis steps before they are
 // consumed (`complete`), so the memory latency is covered by the steps in between; `complete`
 // twists, writes the new raw words back in place, tempers them and appends them to a 64-slot ring
 // of ready words in LDS together with one accept bit per slot ((w & maskN) <= N-1, the masked
@@ -818,14 +818,15 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         vam[t] = inb && PACKED ? full << (pm[t] & 31) : 0u;
     }
 
-    // Stream upkeep cadence.  A block of 16 words per two steps feeds 8 words per step; a board step uses
-    // 3 (mask + 1) / N + 2 words on average (three masked-rejection draws and the uniform): 6.1 at N = 12, but 7.3 .. 7.7 at
-    // N = 9, 17, 18, 19, where the mask accepts little more than half of the words.  Those sizes, like full_3d (8.1 words per
-    // step), run the upkeep on every step; a block then lands one step after it was requested, so it is requested earlier.
-    const bool every_step = MODE == MCQ_MODE_FULL3D || 3u * (maskN + 1u) > 5u * (unsigned)N;
-    // a block needs gen - pos <= 48 when it lands: requested at <= 58 two board steps (>= 10 words) earlier, or one step earlier at
-    // <= 53 (board, >= 5 words per step) / <= 54 (full_3d, >= 6)
-    const uint32_t room_limit = !every_step ? 58u : MODE == MCQ_MODE_BOARD ? 53u : 54u;
+    // Stream upkeep cadence: demand-driven.  The upkeep code (finish the block in flight, request the next one) runs in a step
+    // when some chain of the wavefront is down to fewer than 28 ready words -- every chain with work pending is served then -- and
+    // is skipped otherwise.  A board step uses 3 (mask + 1) / N + 2 words on average (6.1 at N = 12, 7.7 at N = 17), a full_3d
+    // step 8.1, and a block brings 16, so this runs every second or third step with most lanes busy, instead of on a fixed
+    // cadence with half of them idle (full_3d +9 %, board N = 17 +10 %, N = 16 +5 %).  The ring can never be overrun: a block
+    // needs gen - pos <= 48 when it lands, and it is requested at <= 53 (board, >= 5 words used per step) or <= 54 (full_3d, >= 6)
+    // at least one step earlier; running dry is handled by the sequential path, which services the stream itself.
+    const uint32_t room_limit = MODE == MCQ_MODE_BOARD ? 53u : 54u;
+    constexpr uint32_t LOW_WATER = 28;
 
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
@@ -846,13 +847,12 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             uint32_t oldp = 0;
             uint32_t uw1 = 0, uw2 = 0;   // the two words of random()
             int stage_no = 0;
-            // stream upkeep runs for every chain of the wavefront together: board steps use ~6.1 words, so one
-            // block of 16 per two steps keeps up; full_3d steps use ~8.1, so every step
+            // stream upkeep runs for every chain of the wavefront together (cadence: see LOW_WATER above)
             auto upkeep = [&]() {
                 STAMP(0);
                 if (rng.pending) rng.complete();
-                // the block lands at the next upkeep, after >= 10 (board: two steps) or >= 6 (full_3d) more
-                // words were consumed, or earlier only if the ring ran dry: there is room for its 16 words
+                // the block lands at a later upkeep, after at least one more step's words were consumed, or earlier only
+                // if the ring ran dry: there is room for its 16 words
                 if (rng.gen - rng.pos <= room_limit) rng.issue();
                 STAMP(1);  // stream upkeep: complete + issue
             };
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             };
 
-            const bool upkeep_now = every_step || (step & 1) == 0;
+            const bool upkeep_now = wave_any(rng.gen - rng.pos < LOW_WATER);
             bool batched;  // the batched draw below succeeded for this chain
             if constexpr (MODE == MCQ_MODE_BOARD) {
                 // Straight-line for every chain of the wavefront (no divergent branch): positions of the next four
