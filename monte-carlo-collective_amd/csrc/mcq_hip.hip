@@ -810,7 +810,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 #pragma unroll
     for (int t = 0; t < NTP; t++) {
         const int m = (gl & (PG - 1)) + t * PG;
-        const bool inb = m < N;
+        // only the last pass can leave the board: a variant with NT passes runs for ceil(N / PG) == NT, i.e. N > (NT - 1) * PG
+        const bool inb = t + 1 < NTP || m < N;
         const uint32_t full = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
         pm[t] = inb ? m : N - 1;
         krc[t] = inb ? (NARROW ? 0xffffffffu : 0x00010001u) : 0u;
