@@ -9,34 +9,40 @@
 //   run_experiment fan-out  experiments.py:507-546   (chain r seeded with base_seed + r)
 //
 // Design (DESIGN.md has the long form).  A wavefront of 64 lanes is split into groups of G
-// lanes (G = 8 or 16); one group runs one chain, so a wavefront advances 64/G chains in
-// lockstep, one Metropolis step per loop iteration.  What is serial inside a chain (the
-// NumPy-legacy MT19937 stream with its data-dependent word consumption, the proposal, the
-// accept test) is computed redundantly by the G lanes of the group; the attack count and the
-// stream generation are spread over the lanes.
-//   * MT19937: 624 raw state words per chain in LDS.  Words are regenerated G at a time
-//     ("round": every lane twists one word), tempered, and appended to a 64-slot ring of
-//     ready words in LDS, together with one bit per slot that says whether the word passes
-//     the masked-rejection test of randint(0, N).  Rounds run at a fixed cadence for every
-//     chain of the wavefront that has room, so the lanes stay converged.
-//   * proposal (board): the positions of the next four accepted words come from bit tricks
-//     on the 32-slot view of the accept bits (no rejection loop, no divergence); i, j and two
-//     candidates for new_k are fetched in one batch, the uniform's two words sit right after
-//     the chosen candidate.  Anything unusual (ring nearly empty, both candidates equal to
-//     old_k, rejection run longer than the view) takes a sequential fallback that draws word
-//     by word -- same stream, same results.
+// lanes (4, 8 or 16; default 4 for boards up to N = 12, 8 otherwise); one group runs one chain,
+// so a wavefront advances 64/G chains in lockstep, one Metropolis step per loop iteration, one
+// wavefront per workgroup, no barrier anywhere.  What is serial inside a chain (the NumPy-legacy
+// MT19937 stream with its data-dependent word consumption, the proposal, the accept test) is
+// computed redundantly by the G lanes of the group; the attack count and the stream generation
+// are spread over the lanes.
+//   * MT19937: the 624 raw state words of a chain stay in its record in global memory and are
+//     regenerated in place in blocks of 16 (16/G per lane), requested one or more steps before
+//     they are needed; the block is twisted, tempered and appended to a 64-slot ring of ready
+//     words in LDS (its first 32 slots mirrored behind it), together with one bit per slot that
+//     says whether the word passes the masked-rejection test of randint(0, N).  This upkeep is
+//     demand-driven and runs for all chains of the wavefront together, so the lanes stay converged.
+//   * proposal (board): the positions of the next five accepted words come from bit tricks on the
+//     32-slot view of the accept bits (no rejection loop, no divergence); i, j and three
+//     candidates for new_k are fetched in one batch, each candidate with the two words behind it,
+//     which are the uniform's if that candidate is taken.  Anything unusual (ring nearly empty,
+//     all candidates equal to old_k, rejection run longer than the view) takes a sequential
+//     fallback that draws word by word -- same stream, same results.
 //   * dE (board): only columns on the row, column and two diagonals of (i,j) in the ij-plane
 //     can attack cell (i,j,k), at most 4N of them; a column at in-plane distance d with height
 //     h attacks iff |h-k| is 0 or d, i.e. iff bit h of (B | B<<d | B>>d), B = 1<<k, is set.
-//     One lane per (direction, position) probe, then a DPP all-reduce over the group.
+//     One lane per (direction, position) probe, old and new height packed into one register for
+//     N <= 16, then a DPP all-reduce over the group.  full_3d: the same with one occupancy word
+//     per column and popcounts.
 //   * accept: u < exp(-beta dE) is decided in float32 from the top 27 bits of u whenever u is
 //     outside a 2^-10 relative bracket around the float32 estimate; inside the bracket the
 //     float64 exp and the 53-bit u decide, so every decision equals the all-float64 decision.
 //     (MCQ_FLAG_EXACT_EXP disables the bracket.)
 //   * beta(step) is evaluated on the device in float64 by a small kernel into a table that the
 //     sweep reads with scalar loads; strict IEEE (this file is built with -ffp-contract=off).
-//   * energy_history: each group stages G consecutive entries in a register and stores them
-//     as one aligned segment; accept bits are flushed as 64-bit words.
+//   * energy_history: each chain stages 16 entries in LDS and stores them as one aligned 64-byte
+//     segment; accept bits are flushed as 32-bit words.
+//   * pacing: the wavefronts of a SIMD compare their progress through a small table and set
+//     s_setprio so that they finish together (see set_priority below).
 //
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include <hip/hip_runtime.h>
@@ -921,8 +927,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             const bool upkeep_now = wave_any(rng.gen - rng.pos < LOW_WATER);
             bool batched;  // the batched draw below succeeded for this chain
             if constexpr (MODE == MCQ_MODE_BOARD) {
-                // Straight-line for every chain of the wavefront (no divergent branch): positions of the next four
-                // accepted words inside the 32 ring slots that follow pos, i / j / two candidates for new_k, the old
+                // Straight-line for every chain of the wavefront (no divergent branch): positions of the next five
+                // accepted words inside the 32 ring slots that follow pos, i / j / three candidates for new_k, the old
                 // height, and the uniform's two words behind the chosen candidate.  Where the attempt is not valid the
                 // fetched values are simply not used (every address is inside the chain's LDS slice).
                 const uint32_t s = rng.pos & (RING - 1);
