@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--mcmc-type", default="board", choices=["board", "full_3d"])
     ap.add_argument("--schedule", default="linear_annealing")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (4, 8 or 16; 0 = library default)")
+    ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
+                    help="mt19937 = NumPy's stream (reference-identical, the bench default); philox = counter-based fast mode (evidence only)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=1024)
@@ -82,7 +84,7 @@ def main():
     trace = not args.no_trace
     base_seed = 42
     p = abi.make_params(args.N, args.n_steps, "random", sp, args.chains, mcmc_type=args.mcmc_type,
-                        early_stop_patience=None, trace=trace, lanes_per_chain=args.lanes)
+                        early_stop_patience=None, trace=trace, lanes_per_chain=args.lanes, rng=args.rng)
     # chains are sharded by contiguous global index; the seed of a chain does not depend on the GPU count
     seeds = abi.seeds_for(base_seed + rank * args.chains, args.chains)
     run = mcq_amd._lib.DeviceRun(p, seeds, trace=trace, states=False)
@@ -144,7 +146,7 @@ def main():
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}"
+            key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}" + ("" if args.rng == "mt19937" else f"_{args.rng}")
             traffic = tj.get(key, {}).get("bytes_per_launch")
             valu_insts = tj.get(key, {}).get("valu_insts_per_launch")
         except (OSError, ValueError):
@@ -166,7 +168,8 @@ def main():
         "config": {
             "workload": f"single_N N={args.N} mcmc_type={args.mcmc_type} init=random {args.schedule} "
                         f"{sp.get('beta_start', sp.get('beta_const'))}->{sp.get('beta_end', '')} "
-                        f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace else 'none'}",
+                        f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace else 'none'}"
+                        + ("" if args.rng == "mt19937" else f" rng={args.rng} (NOT the reference's stream)"),
             "chains_total": total_chains,
             "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes_n(run.p.mode, run.p.N)),
             "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summary all-reduce (MIN/SUM)",
@@ -199,7 +202,7 @@ def main():
 
         n_cpu = min(args.cpu_chains, args.chains)
         threads = min(16, os.cpu_count() or 1)
-        pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=False)
+        pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=False, rng=args.rng)
         t1 = time.perf_counter()
         cres = oracle.run(pc, seeds[:n_cpu], trace=False, states=False, n_threads=threads)
         dt = time.perf_counter() - t1

@@ -57,6 +57,10 @@ extern "C" {
 
 /* random stream */
 #define MCQ_RNG_MT19937_NUMPY 0 /* NumPy legacy global RandomState: bit-parity with the reference */
+#define MCQ_RNG_PHILOX4X32_10 1 /* counter-based fast mode, NOT a stream of the reference: word w of chain r is
+                                   philox4x32-10(counter = (w / 4, 0, 0, 0), key = (seeds[r], 0))[w % 4], consumed with the same
+                                   rules as the NumPy stream (masked rejection, 53-bit doubles, Fisher-Yates); no generator state
+                                   lives in memory.  Results equal the oracle's in the same mode, not the reference's. */
 
 /* energy_history trace */
 #define MCQ_TRACE_NONE 0 /* only per-chain summaries (measure_min_energy_vs_N discards histories: experiments.py:1061) */
@@ -93,9 +97,10 @@ typedef struct mcq_params {
     double beta_start;       /* annealing schedules          (experiments.py:19-77)  */
     double beta_end;
     int64_t n_steps;         /* steps per chain = schedule length                    */
-    int64_t n_chains;        /* n_runs; chain r is seeded with seeds[r] (= base_seed + r, experiments.py:508) */
+    int64_t n_chains;        /* n_runs (< 2^31); chain r is seeded with seeds[r] (= base_seed + r, experiments.py:508) */
     int64_t patience;        /* early_stop_patience, board only (experiments.py:349-353); < 0 = None */
-    int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1 */
+    int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1 and a multiple of 16 (HIP: rows are
+                                written in aligned 64-byte segments; energy_hist itself must be 64-byte aligned) */
     int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
     int32_t lanes_per_chain; /* HIP only: 4, 8 or 16 lanes of a wavefront per chain; 0 = library default */
     int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
@@ -154,8 +159,8 @@ size_t mcq_workspace_bytes(const mcq_params* p);
 /*
  * Replaces run_experiment's fan-out + per-chain sweep (experiments.py:507-546) with
  * device-resident buffers.  `seeds` (uint32[n_chains]) and every non-NULL pointer of
- * `out` are DEVICE pointers; `workspace` is a device buffer of at least
- * mcq_workspace_bytes(p) bytes.  Work is enqueued on `hip_stream` (a hipStream_t, NULL =
+ * `out` are DEVICE pointers; `workspace` is a 64-byte aligned device buffer of at least
+ * mcq_workspace_bytes(p) bytes (hipMalloc results are).  Violations return MCQ_EINVAL.  Work is enqueued on `hip_stream` (a hipStream_t, NULL =
  * the default stream) and the call returns without synchronising.
  */
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out,
@@ -183,6 +188,14 @@ int mcq_trace_stats_device(const mcq_params* p, const mcq_outputs* out, int64_t*
                            uint64_t* bin_proposed, void* hip_stream);
 
 /*
+ * The beta(step) table the sweep reads (experiments.py:13-77 evaluated on the device in float64, strict IEEE):
+ * `beta_out` is a DEVICE buffer of double[n_sets][n_steps] (n_sets <= 1: [n_steps]); `c32_out` (optional, DEVICE,
+ * float, same shape) receives (float)(-beta * log2(e)), the factor of the float32 accept bracket.  Inspection /
+ * testing only: mcq_run_device computes its own tables.  Enqueued on `hip_stream`; asynchronous.
+ */
+int mcq_beta_table_device(const mcq_params* p, double* beta_out, float* c32_out, void* hip_stream);
+
+/*
  * Same computation with HOST buffers: allocates device memory, uploads seeds, runs,
  * downloads every non-NULL output and frees.  Blocking.  `kernel_seconds` (optional)
  * receives the device time of init + sweep measured with HIP events.
@@ -194,6 +207,8 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
 
 /* CPU restatement of the reference; host buffers; n_threads <= 1 runs chains in the calling thread. */
 int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads);
+/* one Philox-4x32-10 block: ctr[4], key[2] -> out[4] (known-answer tests) */
+int mcq_oracle_philox_block(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
 const char* mcq_oracle_last_error(void);
 
 #ifdef __cplusplus

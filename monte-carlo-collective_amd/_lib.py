@@ -47,8 +47,14 @@ def lib():
     if _lib is None:
         _share_torch_hip_runtime()
         so = _build.SO
-        diag = os.environ.get("MCQ_DIAG_LIB")  # a diagnostic build of the same library (tools/stamp_profile.sh); never the oracle
+        # A diagnostic build of the same library (tools/stamp_profile.sh, tools/wave_times.sh).  Swapping the product library
+        # through the environment is opt-in: without MCQ_ALLOW_DIAG=1 the variable is refused, not silently honoured.
+        diag = os.environ.get("MCQ_DIAG_LIB")
         if diag:
+            if os.environ.get("MCQ_ALLOW_DIAG") != "1":
+                raise McqError("MCQ_DIAG_LIB is set but MCQ_ALLOW_DIAG=1 is not: refusing to replace libmcq_hip.so")
+            if "oracle" in os.path.basename(diag):
+                raise McqError("MCQ_DIAG_LIB must be a build of csrc/mcq_hip.hip, never the oracle")
             so = diag
         elif _build.stale():
             try:
@@ -79,6 +85,8 @@ def lib():
         L.mcq_trace_stats_device.restype = C.c_int
         L.mcq_trace_stats_device.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Outputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_beta_table_device.restype = C.c_int
+        L.mcq_beta_table_device.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_run_host.restype = C.c_int
         L.mcq_run_host.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.POINTER(C.c_double)]
         if L.mcq_abi_version() != abi.ABI_VERSION:
@@ -100,6 +108,25 @@ def _check(rc):
 
 def device_count():
     return lib().mcq_device_count()
+
+
+def beta_table_device(params):
+    """The beta(step) table(s) the sweep reads, computed on the GPU (mcq_beta_table_device): float64 [n_steps] or
+    [n_sets, n_steps], plus the float32 factor table of the accept bracket.  Inspection / tests."""
+    import torch
+
+    L = lib()
+    p = abi.copy_params(params)
+    sets = max(1, int(p.n_sets))
+    n = int(p.n_steps)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    b = torch.zeros(sets * n, dtype=torch.float64, device=dev)
+    c = torch.zeros(sets * n, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+    _check(L.mcq_beta_table_device(C.byref(p), b.data_ptr(), c.data_ptr(), C.c_void_p(st.cuda_stream)))
+    st.synchronize()
+    shape = (sets, n) if sets > 1 else (n,)
+    return b.cpu().numpy().reshape(shape), c.cpu().numpy().reshape(shape)
 
 
 def run_host(params, seeds, trace=True, states=True):

@@ -22,6 +22,8 @@ SCHED = {
     "sinusoidal_annealing": 4,
 }
 RNG_MT19937_NUMPY = 0
+RNG_PHILOX4X32_10 = 1
+RNG = {"mt19937": RNG_MT19937_NUMPY, "numpy": RNG_MT19937_NUMPY, "philox": RNG_PHILOX4X32_10}
 TRACE_NONE, TRACE_I32, TRACE_REDUCED = 0, 1, 2
 FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
@@ -181,7 +183,7 @@ def _check_schedule(schedule_params):
 
 
 def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_type="full_3d", early_stop_patience=None,
-                     trace=True, flags=0, lanes_per_chain=0, device=-1):
+                     trace=True, flags=0, lanes_per_chain=0, device=-1, rng="mt19937"):
     """Parameters of ONE launch that runs `chains_per_set` chains under each schedule of `schedule_sets` (a list of
     betta_scheduling dicts): chains [t * chains_per_set, (t + 1) * chains_per_set) follow schedule t.  What
     run_beta_start_end_pairs does pair by pair (experiments.py:741-846), batched."""
@@ -191,7 +193,8 @@ def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_
     if chains_per_set <= 0 or chains_per_set % 16:
         raise ValueError("chains_per_set must be a positive multiple of 16")
     p = make_params(N, n_steps, init_mode, schedule_sets[0], chains_per_set * len(sets), mcmc_type=mcmc_type,
-                    early_stop_patience=early_stop_patience, trace=trace, flags=flags, lanes_per_chain=lanes_per_chain, device=device)
+                    early_stop_patience=early_stop_patience, trace=trace, flags=flags, lanes_per_chain=lanes_per_chain, device=device,
+                    rng=rng)
     arr = (Schedule * len(sets))()
     for a, (st, bc, bs, be) in zip(arr, sets):
         a.sched, a.reserved, a.beta_const, a.beta_start, a.beta_end = SCHED[st], 0, bc, bs, be
@@ -202,7 +205,7 @@ def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_
 
 
 def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="full_3d", early_stop_patience=None,
-                trace=True, flags=0, lanes_per_chain=0, device=-1):
+                trace=True, flags=0, lanes_per_chain=0, device=-1, rng="mt19937"):
     """Build a Params from the reference's vocabulary.  Raises ValueError exactly where the
     reference does: unknown schedule type (experiments.py:105), missing beta parameters
     (experiments.py:85-102), unknown init_mode (mcmc_board.py:59, mcmc.py:104)."""
@@ -233,7 +236,9 @@ def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="ful
     p.mode = mode_of(mcmc_type)
     p.init = INIT[init_mode]
     p.sched = SCHED[st]
-    p.rng = RNG_MT19937_NUMPY
+    if rng not in RNG:
+        raise ValueError(f"Unknown rng: {rng}")
+    p.rng = RNG[rng]
     p.trace = trace_mode(trace)
     p.flags = flags
     p.beta_const = float(bc) if bc is not None else 0.0

@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -108,7 +109,7 @@ constexpr int REC_E0 = 627;       // record word: initial energy
 constexpr int REC_STATE = 628;    // first word of the state bytes (heights or (i,j,k) triplets)
 
 struct KArgs {
-    int N, Q, mode, init, sched;
+    int N, Q, mode, init, sched, rng;
     unsigned flags;
     unsigned maskN, maskQ;  // smallest 2^b - 1 >= N-1 / Q-1 (masked rejection)
     int klarner_M;          // 0: exact Klarner (gcd(N,210)==1); else core edge M
@@ -159,14 +160,38 @@ __device__ __forceinline__ unsigned mask_for(unsigned m) {
     return mask;
 }
 
+// Philox-4x32-10 (Salmon et al., SC'11) with counter (c0, c1, 0, 0) and key (k0, 0): the block function of
+// mcq_params.rng == MCQ_RNG_PHILOX4X32_10 (include/mcq.h); oracle/mcq_oracle.c holds the same function and its known answers.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t (&out)[4]) {
+    uint32_t c2 = 0u, c3 = 0u, k1 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
 // Stream used by the init kernel: one wavefront per chain, the current 64-word block kept in a
 // register per lane, one ds_bpermute per draw.
 struct InitRng {
     uint32_t* mt;
     uint32_t win;
     int pos, gen_end, lane;
+    bool philox;
+    uint32_t key;
 
     __device__ __forceinline__ void fill(int base) {
+        if (philox) {  // word base + lane of the chain's Philox stream (an init draws far fewer than 2^32 words)
+            uint32_t o[4];
+            const uint32_t w = (uint32_t)(base + lane);
+            philox4x32_10(w >> 2, 0u, key, o);
+            win = (w & 2u) ? ((w & 1u) ? o[3] : o[2]) : ((w & 1u) ? o[1] : o[0]);
+            return;
+        }
         const int i = base + lane;
         if (i < MT_N) {
             uint32_t v;
@@ -185,7 +210,7 @@ struct InitRng {
         if (off == 0) fill(pos);
         const uint32_t w = (uint32_t)__shfl((int)win, off, 64);
         pos++;
-        if (pos == MT_N) pos = 0, gen_end = 0;
+        if (!philox && pos == MT_N) pos = 0, gen_end = 0;
         return w;
     }
     // RandomState.randint(0, m + 1) / shuffle's random_interval: masked rejection on 32-bit words;
@@ -239,7 +264,7 @@ __global__ __launch_bounds__(256) void mcq_beta_kernel(KArgs a) {
     if (s < a.n_steps) {
         const double b = beta_at(a, s);
         a.beta_tab[s] = b;
-        a.c32_tab[s] = (float)(-b * 1.4426950408889634);
+        if (a.c32_tab) a.c32_tab[s] = (float)(-b * 1.4426950408889634);
     }
 }
 
@@ -296,6 +321,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     }
     InitRng rng;
     rng.mt = mt, rng.win = 0, rng.pos = 0, rng.gen_end = 0, rng.lane = lane;  // NumPy's pos == 624: the first draw starts a generation
+    rng.philox = a.rng == MCQ_RNG_PHILOX4X32_10, rng.key = a.seeds[chain];
 
     const unsigned mN = (unsigned)(N - 1);
     if (a.mode == MCQ_MODE_BOARD) {
@@ -484,7 +510,10 @@ __device__ __forceinline__ uint32_t group_or(uint32_t u) {
 // rejection test of randint(0, N)).
 //   pos, gen   absolute counters of consumed / generated words; ring slot = counter & 63
 //   gi         MT index of the next block to generate (multiple of 16, wraps at 624)
-template <int G, bool HASQ>
+//
+// PHILOX (mcq_params.rng == MCQ_RNG_PHILOX4X32_10): the same ring, but a block of 16 words is computed from the chain's
+// word counter (`generate`) instead of being regenerated from a state in memory: no issue / complete, no record traffic.
+template <int G, bool HASQ, bool PHILOX = false>
 struct Stream {
     static constexpr int WPL = 16 / G;  // words per lane in a block
     char* wbase;    // wave-uniform: record of the wavefront's first chain (kept in scalar registers)
@@ -501,6 +530,7 @@ struct Stream {
     uint32_t tc1, tc2;  // tempering masks, kept in scalar registers so that (y << s) & c ^ y is one 3-input op
     uint32_t tlow, tmat;   // 0x7fffffff and the twist matrix 0x9908b0df, scalar registers as well
     uint32_t okM4, okK4;   // maskN and 0x80 + (N - 1) in each byte: four randint(0, N) accept tests in one subtraction
+    uint32_t pkey, gen_hi;  // PHILOX: the chain's key (its seed); bits 32.. of the generated-word counter
 
     __device__ __forceinline__ uint32_t temper(uint32_t y) const {
         y ^= y >> 11;
@@ -558,6 +588,51 @@ struct Stream {
         pending = true;
     }
 
+    // PHILOX: the next 16 words of the chain's stream straight from the counter; append to the ring.  Needs gen - pos <= 48.
+    // Word w of the stream is element w % 4 of block w / 4; a lane computes the block that holds its WPL words.
+    __device__ __forceinline__ void generate() {
+        uint32_t o[4], t[WPL];
+        const uint32_t blk = (gen >> 2) | (gen_hi << 30);  // gen is a multiple of 16: the low two bits of blk are free for the lane's part
+        philox4x32_10(blk | ((uint32_t)(gl * WPL) >> 2), gen_hi >> 2, pkey, o);
+        if constexpr (WPL == 4) {
+            t[0] = o[0], t[1] = o[1], t[2] = o[2], t[3] = o[3];
+        } else if constexpr (WPL == 2) {
+            t[0] = (gl & 1) ? o[2] : o[0], t[1] = (gl & 1) ? o[3] : o[1];
+        } else {
+            t[0] = (gl & 2) ? ((gl & 1) ? o[3] : o[2]) : ((gl & 1) ? o[1] : o[0]);
+        }
+        append(t);
+        gen_hi += gen == 0u ? 1u : 0u;  // gen has just advanced by 16
+    }
+
+    // tempered words of a block -> ring slots [gen, gen + 16) (+ mirror) and their accept bits; advances gen
+    __device__ __forceinline__ void append(const uint32_t (&t)[WPL]) {
+        const int so = gen & (RING - 1);
+        uint32_t bits = 0, bitsq = 0;
+        uint32_t* slot = ring + so + gl * WPL;
+        uint32_t* mirror = ring + (so < RING_MIRROR ? so + RING : so) + gl * WPL;  // mirror of slots 0..31 (otherwise the same store again)
+        if constexpr (WPL == 4) {
+            *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
+            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
+            const uint32_t b01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x04000c0cu);
+            const uint32_t d = okK4 - ((b01 | b23) & okM4);
+            bits = __builtin_amdgcn_udot4((d >> 7) & 0x01010101u, 0x08040201u, 0u, false) << (gl * 4);
+        } else {
+#pragma unroll
+            for (int w = 0; w < WPL; w++) {
+                slot[w] = t[w], mirror[w] = t[w];
+                bits |= ((t[w] & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
+            }
+        }
+        if (HASQ) {
+#pragma unroll
+            for (int w = 0; w < WPL; w++) bitsq |= ((t[w] & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
+        }
+        set_field(ok_lo, ok_hi, so, group_or<G>(bits));
+        if (HASQ) set_field(okq_lo, okq_hi, so, group_or<G>(bitsq));
+        gen += 16;
+    }
+
     // twist + temper the block loaded by issue(); append to the ring.  Needs gen - pos <= 48.
     __device__ __forceinline__ void complete() {
         const int i0 = gi + gl * WPL;
@@ -600,6 +675,14 @@ struct Stream {
         pending = false;
     }
 
+    // PHILOX: continue the stream at word rpos (the init kernel consumed the words before it): the 16-word group that holds
+    // rpos is generated again and the words in front of rpos are skipped.
+    __device__ __forceinline__ void attach_philox(uint32_t key, uint32_t rpos) {
+        pkey = key, pos = rpos, gen = rpos & ~15u, gen_hi = 0, gi = 0;
+        generate();
+        generate();
+    }
+
     // continue the stream of a chain record: words [rpos, rge) of the current generation are already
     // twisted but not consumed (fewer than 64 of them); temper them into the ring.
     __device__ __forceinline__ void attach(char* wave_base, uint32_t chain_off, uint32_t* lds_ring, int rpos, int rge, int gl_, unsigned maskN_,
@@ -611,8 +694,10 @@ struct Stream {
         okq_lo = okq_hi = 0;
         pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge;
         ok_lo = ok_hi = 0, pending = false, pn = 0;
+        pkey = 0, gen_hi = 0;
 #pragma unroll
         for (int w = 0; w < WPL; w++) pa[w] = px[w] = 0;
+        if constexpr (PHILOX) return;  // attach_philox() follows
         for (int t0 = rpos & ~15; t0 < rge; t0 += 16) {
             uint32_t bits = 0, bitsq = 0;
 #pragma unroll
@@ -713,7 +798,8 @@ __global__ __launch_bounds__(256) void mcq_reduced_finalize_kernel(const unsigne
 // (all their LDS reads in flight together); NT == 0: run-time loop over the probe passes.
 // REDUCED: trace == MCQ_TRACE_REDUCED (per-entry sums accumulated in the sweep); a separate instantiation so that the
 // default kernels carry none of its code.
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED>
+// PHILOX: mcq_params.rng == MCQ_RNG_PHILOX4X32_10 (the stream is computed, not read from the chain record).
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false>
 __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     WAVE_T0;
     // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
@@ -767,8 +853,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     asm volatile("" : "+s"(tc1), "+s"(tc2));  // opaque scalars: no literal operands in the tempering
     const uint32_t rec_bytes = (uint32_t)a.rec_words * 4u;
     char* wave_base = (char*)(a.ws + (long long)blockIdx.x * CPW * (long long)a.rec_words);
-    Stream<G, MODE == MCQ_MODE_FULL3D> rng;
+    Stream<G, MODE == MCQ_MODE_FULL3D, PHILOX> rng;
     rng.attach(wave_base, active ? (uint32_t)grp * rec_bytes : 0u, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN, maskQ, mQ, tc1, tc2);
+    if constexpr (PHILOX) rng.attach_philox(a.seeds[crow], rec[REC_POS]);
 
     int E = (int)rec[REC_E0];
     int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
@@ -832,7 +919,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     // cadence with half of them idle (full_3d +9 %, board N = 17 +10 %, N = 16 +5 %).  The ring can never be overrun: a block
     // needs gen - pos <= 48 when it lands, and it is requested at <= 53 (board, >= 5 words used per step) or <= 54 (full_3d, >= 6)
     // at least one step earlier; running dry is handled by the sequential path, which services the stream itself.
-    const uint32_t room_limit = MODE == MCQ_MODE_BOARD ? 53u : 54u;
+    // (PHILOX: the block is generated on the spot, so it needs its room right away: gen - pos <= 48)
+    const uint32_t room_limit = PHILOX ? 48u : MODE == MCQ_MODE_BOARD ? 53u : 54u;
     constexpr uint32_t LOW_WATER = 28;
 
     STAMP_DECL;
@@ -857,10 +945,14 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             // stream upkeep runs for every chain of the wavefront together (cadence: see LOW_WATER above)
             auto upkeep = [&]() {
                 STAMP(0);
-                if (rng.pending) rng.complete();
-                // the block lands at a later upkeep, after at least one more step's words were consumed, or earlier only
-                // if the ring ran dry: there is room for its 16 words
-                if (rng.gen - rng.pos <= room_limit) rng.issue();
+                if constexpr (PHILOX) {
+                    if (rng.gen - rng.pos <= room_limit) rng.generate();
+                } else {
+                    if (rng.pending) rng.complete();
+                    // the block lands at a later upkeep, after at least one more step's words were consumed, or earlier only
+                    // if the ring ran dry: there is room for its 16 words
+                    if (rng.gen - rng.pos <= room_limit) rng.issue();
+                }
                 STAMP(1);  // stream upkeep: complete + issue
             };
             // sequential draws: one word at a time from what the ring holds, topping it up when it runs dry
@@ -1361,10 +1453,11 @@ int validate(const mcq_params* p) {
     if (p->mode != MCQ_MODE_BOARD && p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "unknown mcmc_type");
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL) return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
-    if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "unknown rng");
+    if (p->rng != MCQ_RNG_MT19937_NUMPY && p->rng != MCQ_RNG_PHILOX4X32_10) return fail(MCQ_EINVAL, "unknown rng");
     if (p->trace != MCQ_TRACE_NONE && p->trace != MCQ_TRACE_I32 && p->trace != MCQ_TRACE_REDUCED) return fail(MCQ_EINVAL, "unknown trace mode");
     if (p->n_steps < 0 || p->n_steps > 2147483000LL) return fail(MCQ_EINVAL, "n_steps out of range [0, 2^31)");
     if (p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_chains");
+    if (p->n_chains > 2147483647LL) return fail(MCQ_EINVAL, "n_chains out of range [0, 2^31)");  // one workgroup per chain in the init kernel
     if (p->lanes_per_chain != 0 && p->lanes_per_chain != 4 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
         return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 4, 8 or 16");
     if (p->n_sets < 0) return fail(MCQ_EINVAL, "negative n_sets");
@@ -1403,7 +1496,7 @@ int chain_lds_words_for(int N, int mode, bool narrow) {
 
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
     memset(a, 0, sizeof *a);
-    a->N = p->N, a->Q = p->N * p->N, a->mode = p->mode, a->init = p->init, a->sched = p->sched, a->flags = p->flags;
+    a->N = p->N, a->Q = p->N * p->N, a->mode = p->mode, a->init = p->init, a->sched = p->sched, a->flags = p->flags, a->rng = p->rng;
     a->maskN = host_mask((unsigned)(p->N - 1)), a->maskQ = host_mask((unsigned)(a->Q - 1));
     a->klarner_M = 0;
     if (p->init == MCQ_INIT_KLARNER && gcd_int(p->N, 210) != 1) {
@@ -1448,7 +1541,7 @@ int device_simds() {
     return 4 * cus;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -1458,15 +1551,40 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
 
+// Philox mode (evidence / fast mode, never the reference's stream): the variants of BASELINE's two single_N shapes are
+// specialised (board N = 9..12 at 4 lanes, full_3d N = 9..12 at 8 lanes, no early stop, full or no trace); everything else takes
+// the run-time probe loop.
+template <int MODE, int G>
+int launch_sweep_philox(const KArgs& a, hipStream_t s) {
+    if constexpr (MODE == MCQ_MODE_FULL3D) {
+        if constexpr (G == 8) {
+            if (!a.red && (a.N + 3) / 4 == 3) {
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+                return launch_sweep<MODE, G, false, 3, false, true>(b, s);
+            }
+        }
+        return a.red ? launch_sweep<MODE, G, false, 0, true, true>(a, s) : launch_sweep<MODE, G, false, 0, false, true>(a, s);
+    } else {
+        const bool pat = a.patience >= 0;
+        if constexpr (G == 4) {
+            if (!pat && !a.red && (a.N + 3) / 4 == 3) return launch_sweep<MODE, G, false, 3, false, true>(a, s);
+        }
+        if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true, true>(a, s) : launch_sweep<MODE, G, false, 0, true, true>(a, s);
+        return pat ? launch_sweep<MODE, G, true, 0, false, true>(a, s) : launch_sweep<MODE, G, false, 0, false, true>(a, s);
+    }
+}
+
 template <int MODE, int G>
 int launch_sweep_g(const KArgs& a, hipStream_t s) {
+    if (a.rng == MCQ_RNG_PHILOX4X32_10) return launch_sweep_philox<MODE, G>(a, s);
     if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
         if constexpr (G == 8) {  // N <= 16: 16-bit column words, four lanes around each of the two cells
             const int nt = (a.N + 3) / 4;
@@ -1529,9 +1647,13 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (rc != MCQ_OK) return rc;
     if (!seeds || !out || !workspace) return fail(MCQ_EINVAL, "null argument");
     if (workspace_bytes < mcq_workspace_bytes(p)) return fail(MCQ_ENOMEM, "workspace too small");
+    // the sweep reads the MT words of a record with 16-byte loads and flushes the trace in aligned 64-byte segments
+    if (((uintptr_t)workspace & 63u) != 0) return fail(MCQ_EINVAL, "workspace must be 64-byte aligned");
     if (p->trace == MCQ_TRACE_I32) {
         if (!out->energy_hist || !out->accept_bits) return fail(MCQ_EINVAL, "trace requested without buffers");
         if (p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
+        if (p->hist_stride % 16 != 0) return fail(MCQ_EINVAL, "hist_stride must be a multiple of 16");
+        if (((uintptr_t)out->energy_hist & 63u) != 0) return fail(MCQ_EINVAL, "energy_hist must be 64-byte aligned");
         if (p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
     }
     if (p->trace == MCQ_TRACE_REDUCED && (!out->step_sum || !out->step_sumsq || !out->step_accepted || !out->step_count))
@@ -1626,8 +1748,15 @@ int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs
 
 int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
                          size_t workspace_bytes, void* hip_stream, float* init_ms, float* sweep_ms) {
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    struct Events {  // destroyed on every return path
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        ~Events() {
+            for (auto& e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } evs;
+    hipEvent_t* ev = evs.ev;
+    for (int t = 0; t < 3; t++) HIP_TRY(hipEventCreate(&ev[t]));
 #ifdef MCQ_STAMPS
     if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 64));
     HIP_TRY(hipMemset(g_dbg, 0, 64));
@@ -1653,7 +1782,12 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     if (rc == MCQ_OK) {  // one line per wavefront: start and end in 10 ns ticks from the first start, XCC, SE, CU, SIMD
         HIP_TRY(hipDeviceSynchronize());
         unsigned long long* h = (unsigned long long*)malloc(wt_waves * 32);
-        HIP_TRY(hipMemcpy(h, g_dbg, wt_waves * 32, hipMemcpyDeviceToHost));
+        if (!h) return fail(MCQ_ENOMEM, "out of host memory");
+        const hipError_t ce = hipMemcpy(h, g_dbg, wt_waves * 32, hipMemcpyDeviceToHost);
+        if (ce != hipSuccess) {
+            free(h);
+            return fail(MCQ_EDEVICE, "hipMemcpy: %s", hipGetErrorString(ce));
+        }
         unsigned long long t0 = ~0ull;
         for (size_t w = 0; w < wt_waves; w++)
             if (h[4 * w + 1] && h[4 * w] < t0) t0 = h[4 * w];
@@ -1675,7 +1809,6 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
         if (e == hipSuccess) e = hipEventElapsedTime(&b, ev[1], ev[2]);
         if (e != hipSuccess) rc = fail(MCQ_EDEVICE, "event timing: %s", hipGetErrorString(e));
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     if (init_ms) *init_ms = a;
     if (sweep_ms) *sweep_ms = b;
     return rc;
@@ -1710,6 +1843,26 @@ int mcq_trace_stats_device(const mcq_params* p, const mcq_outputs* out, int64_t*
             HIP_TRY(hipGetLastError());
         }
     }
+    return MCQ_OK;
+}
+
+int mcq_beta_table_device(const mcq_params* p, double* beta_out, float* c32_out, void* hip_stream) {
+    int rc = validate(p);
+    if (rc != MCQ_OK) return rc;
+    if (!beta_out) return fail(MCQ_EINVAL, "null argument");
+    if (p->n_steps == 0) return MCQ_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_steps = p->n_steps;
+    for (size_t t = 0; t < n_sets_of(p); t++) {
+        if (p->n_sets > 1) a.sched = p->sets[t].sched, a.beta_const = p->sets[t].beta_const, a.beta_start = p->sets[t].beta_start, a.beta_end = p->sets[t].beta_end;
+        else a.sched = p->sched, a.beta_const = p->beta_const, a.beta_start = p->beta_start, a.beta_end = p->beta_end;
+        a.beta_tab = beta_out + t * (size_t)p->n_steps;
+        a.c32_tab = c32_out ? c32_out + t * (size_t)p->n_steps : nullptr;
+        hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
 

@@ -81,9 +81,58 @@ static uint32_t mt_u32(mt_t* s) {
     return y;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123
+ * library's philox4x32_R(10, ...)): the counter-based generator of mcq_params.rng == MCQ_RNG_PHILOX4X32_10.  NOT a
+ * stream of the reference (which only has NumPy's MT19937): it exists to run the same sweep without a generator state
+ * in memory; parity in this mode is HIP == this file.  Known answers of the block function: tests/test_oracle_rng.py.
+ * Stream convention: word w of a chain = philox(counter = (w / 4 low, w / 4 high, 0, 0), key = (seed, 0))[w % 4].
+ * ---------------------------------------------------------------------------------------- */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+int mcq_oracle_philox_block(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    philox4x32_10(ctr, key, out);
+    return 0;
+}
+
+/* One chain's random stream: NumPy's MT19937 (the reference's) or the Philox word stream. */
+typedef struct {
+    int kind;     /* MCQ_RNG_* */
+    mt_t mt;
+    uint32_t key; /* philox: the chain's seed */
+    uint64_t w;   /* philox: index of the next word */
+    uint32_t buf[4];
+} rng_t;
+
+static void rng_seed(rng_t* s, int kind, uint32_t seed) {
+    s->kind = kind;
+    if (kind == MCQ_RNG_PHILOX4X32_10) s->key = seed, s->w = 0;
+    else mt_seed(&s->mt, seed);
+}
+
+static uint32_t rng_u32(rng_t* s) {
+    if (s->kind != MCQ_RNG_PHILOX4X32_10) return mt_u32(&s->mt);
+    if ((s->w & 3) == 0) {
+        const uint64_t blk = s->w >> 2;
+        const uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u}, key[2] = {s->key, 0u};
+        philox4x32_10(ctr, key, s->buf);
+    }
+    return s->buf[s->w++ & 3];
+}
+
 /* Masked rejection on 32-bit words, as RandomState.randint(0, m+1) and shuffle use for
  * ranges below 2^32: m == 0 consumes nothing. */
-static uint32_t mt_bounded(mt_t* s, uint32_t m) {
+static uint32_t mt_bounded(rng_t* s, uint32_t m) {
     if (m == 0) return 0;
     uint32_t mask = m;
     mask |= mask >> 1;
@@ -93,24 +142,25 @@ static uint32_t mt_bounded(mt_t* s, uint32_t m) {
     mask |= mask >> 16;
     uint32_t v;
     do {
-        v = mt_u32(s) & mask;
+        v = rng_u32(s) & mask;
     } while (v > m);
     return v;
 }
 
 /* np.random.random(): 53-bit double from two words, high part first. */
-static double mt_double(mt_t* s) {
-    uint32_t a = mt_u32(s) >> 5, b = mt_u32(s) >> 6;
+static double mt_double(rng_t* s) {
+    uint32_t a = rng_u32(s) >> 5, b = rng_u32(s) >> 6;
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 
 /* exported for tests/test_oracle_rng.py: kind 0 = raw u32, 1 = bounded(arg), 2 = double */
 int mcq_oracle_rng_stream(uint32_t seed, int kind, uint32_t arg, int64_t n, uint32_t* out_u32,
                           double* out_f64) {
-    mt_t s;
-    mt_seed(&s, seed);
+    rng_t s; /* kind + 16 selects the Philox word stream */
+    rng_seed(&s, kind >= 16 ? MCQ_RNG_PHILOX4X32_10 : MCQ_RNG_MT19937_NUMPY, seed);
+    kind &= 15;
     for (int64_t t = 0; t < n; t++) {
-        if (kind == 0) out_u32[t] = mt_u32(&s);
+        if (kind == 0) out_u32[t] = rng_u32(&s);
         else if (kind == 1) out_u32[t] = mt_bounded(&s, arg);
         else out_f64[t] = mt_double(&s);
     }
@@ -180,7 +230,7 @@ static int iabs(int v) { return v < 0 ? -v : v; }
 /* ------------------------------------------------------------------------------------------
  * Board chain: State3DQueensBoard (mcmc_board.py) + metropolis_mcmc_board (experiments.py:282-376)
  * ---------------------------------------------------------------------------------------- */
-static int board_init(int N, int init, mt_t* rng, int* h) {
+static int board_init(int N, int init, rng_t* rng, int* h) {
     if (init == MCQ_INIT_RANDOM) { /* mcmc_board.py:28: N*N bounded draws, row-major */
         for (int c = 0; c < N * N; c++) h[c] = (int)mt_bounded(rng, (uint32_t)(N - 1));
     } else if (init == MCQ_INIT_LATIN) { /* mcmc_board.py:30-31 */
@@ -253,7 +303,7 @@ static int64_t ulp_distance(double a, double b) {
 }
 
 /* experiments.py:238-239 / 326-327: the uniform is drawn on every step */
-static int accept_move(mt_t* rng, double beta, int dE, int64_t* near_ties) {
+static int accept_move(rng_t* rng, double beta, int dE, int64_t* near_ties) {
     double e = exp(-beta * (double)dE);
     double prob = e < 1.0 ? e : 1.0; /* min(1.0, e); NaN cannot occur for finite beta */
     double u = mt_double(rng);
@@ -269,8 +319,8 @@ static int run_board_chain(const job_t* jb, int64_t r) {
     int* best_h = h + Q;
     if (!h) return MCQ_ENOMEM;
 
-    mt_t rng;
-    mt_seed(&rng, jb->seeds[r]); /* experiments.py:287-288 */
+    rng_t rng;
+    rng_seed(&rng, p->rng, jb->seeds[r]); /* experiments.py:287-288 */
     if (board_init(N, p->init, &rng, h) != 0) {
         free(h);
         return MCQ_EINVAL;
@@ -359,7 +409,7 @@ static int full_attacks(cell_t a, cell_t b) {
     return same_ij | same_ik | same_jk | plane_k | plane_j | plane_i | space;
 }
 
-static int full_init(int N, int init, mt_t* rng, cell_t* q, uint8_t* occ) {
+static int full_init(int N, int init, rng_t* rng, cell_t* q, uint8_t* occ) {
     const int Q = N * N;
     memset(occ, 0, (size_t)N * N * N);
     if (init == MCQ_INIT_LATIN) { /* mcmc.py:28-34 */
@@ -449,8 +499,8 @@ static int run_full_chain(const job_t* jb, int64_t r) {
     }
     cell_t* best_q = q + Q;
 
-    mt_t rng;
-    mt_seed(&rng, jb->seeds[r]); /* experiments.py:200-201 */
+    rng_t rng;
+    rng_seed(&rng, p->rng, jb->seeds[r]); /* experiments.py:200-201 */
     if (full_init(N, p->init, &rng, q, occ) != 0) {
         free(q);
         free(occ);
@@ -574,7 +624,7 @@ int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs
             if (p->sets[t].sched < MCQ_SCHED_CONSTANT || p->sets[t].sched > MCQ_SCHED_SINUSOIDAL)
                 return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
     }
-    if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "unknown rng");
+    if (p->rng != MCQ_RNG_MT19937_NUMPY && p->rng != MCQ_RNG_PHILOX4X32_10) return fail(MCQ_EINVAL, "unknown rng");
     if (p->n_steps < 0 || p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_steps / n_chains");
     if (out->energy_hist && p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
     if (out->accept_bits && p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");

@@ -39,6 +39,8 @@ def lib():
         L.mcq_oracle_last_error.restype = C.c_char_p
         L.mcq_oracle_rng_stream.restype = C.c_int
         L.mcq_oracle_rng_stream.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mcq_oracle_philox_block.restype = C.c_int
+        L.mcq_oracle_philox_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_oracle_beta_table.restype = C.c_int
         L.mcq_oracle_beta_table.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.c_int64, C.c_void_p]
         _lib = L
@@ -63,9 +65,18 @@ def run(params, seeds, trace=True, states=True, n_threads=1):
     return arrays
 
 
-def rng_stream(seed, kind, n, arg=0):
-    """kind: 'u32' raw words, 'bounded' masked-rejection integers in [0, arg], 'double'."""
-    code = {"u32": 0, "bounded": 1, "double": 2}[kind]
+def philox_block(ctr, key):
+    """One Philox-4x32-10 block: (4 counter words, 2 key words) -> 4 output words."""
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().mcq_oracle_philox_block(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def rng_stream(seed, kind, n, arg=0, rng="mt19937"):
+    """kind: 'u32' raw words, 'bounded' masked-rejection integers in [0, arg], 'double'; rng 'mt19937' or 'philox'."""
+    code = {"u32": 0, "bounded": 1, "double": 2}[kind] + (16 if rng == "philox" else 0)
     u = np.zeros(n, dtype=np.uint32)
     d = np.zeros(n, dtype=np.float64)
     lib().mcq_oracle_rng_stream(int(seed), code, int(arg), n, u.ctypes.data, d.ctypes.data)

@@ -61,3 +61,18 @@ def test_pure_helpers_without_gpu():
     p.N = 99
     assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0
     assert b"N out of range" in L.mcq_last_error()
+
+
+def test_n_chains_bound_and_diag_gate():
+    """n_chains >= 2^31 is MCQ_EINVAL (one workgroup per chain in the init kernel); MCQ_DIAG_LIB alone does not swap the library."""
+    import subprocess
+    import sys
+
+    L = mcq_amd._lib.lib()
+    p = mcq_amd.abi.make_params(6, 10, "random", {"type": "constant", "beta_const": 1.0}, 2**31, mcmc_type="board")
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and b"n_chains out of range" in L.mcq_last_error()
+    code = "import mcq_amd\ntry:\n    mcq_amd._lib.lib()\n    print('loaded')\nexcept mcq_amd._lib.McqError as e:\n    print('refused', e)\n"
+    env = dict(os.environ, MCQ_DIAG_LIB="/nonexistent/libmcq_hip_x.so")
+    env.pop("MCQ_ALLOW_DIAG", None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True).stdout
+    assert out.startswith("refused") and "MCQ_ALLOW_DIAG" in out

@@ -247,3 +247,55 @@ def test_long_runs_full_trace():
         got, _ = mcq_amd._lib.run_host(p, seeds)
         util.assert_results_equal(got, want, f"long run {mode}")
         assert got["near_ties"].sum() == 0
+
+
+def test_device_beta_tables_against_the_reference(golden):
+    """The table the sweep reads (mcq_beta_kernel through mcq_beta_table_device) against the reference's own closures
+    (experiments.py:13-77, tests/golden/beta.npz): bit-equal for constant / linear / logarithmic / sinusoidal on the sampled
+    steps; the exponential schedule's exp comes from OCML instead of NumPy's SIMD loop and may differ by 1 ulp (NumPy and
+    glibc already differ by that much), which the near-tie counter of every parity test covers."""
+    z = golden.npz("beta")
+    worst = 0
+    for c in golden.manifest["beta"]:
+        p = abi.make_params(6, c["n_steps"], "random", c["schedule"], 16, mcmc_type="board")
+        tab, c32 = mcq_amd._lib.beta_table_device(p)
+        steps = z[c["key"] + "_steps"]
+        got, want = tab[steps], z[c["key"] + "_beta"]
+        if c["schedule"]["type"] in ("exponential_annealing",):
+            ulp = int(np.abs(got.view(np.int64) - want.view(np.int64)).max())
+            worst = max(worst, ulp)
+            assert ulp <= 1, (c, ulp)
+        else:
+            np.testing.assert_array_equal(got, want, err_msg=str(c))
+        np.testing.assert_array_equal(c32[steps], (-(got * 1.4426950408889634)).astype(np.float32), err_msg=str(c))
+    # schedule sets: one table per set, equal to the single-schedule tables
+    sets = [{"type": "sinusoidal_annealing", "beta_start": s, "beta_end": e} for s, e in ((0.1, 2.0), (0.5, 3.0), (2.0, 8.0))]
+    ps = abi.make_params_sets(6, 777, "random", sets, 16, mcmc_type="board")
+    tabs, _ = mcq_amd._lib.beta_table_device(ps)
+    for t, sp in enumerate(sets):
+        one, _ = mcq_amd._lib.beta_table_device(abi.make_params(6, 777, "random", sp, 16, mcmc_type="board"))
+        np.testing.assert_array_equal(tabs[t], one)
+
+
+def test_buffer_contract_is_checked():
+    """include/mcq.h: hist_stride a multiple of 16, energy_hist and the workspace 64-byte aligned -- violations are MCQ_EINVAL."""
+    import ctypes as C
+
+    import torch
+
+    sp = {"type": "constant", "beta_const": 1.0}
+    p = abi.make_params(6, 100, "random", sp, 4, mcmc_type="board")
+    run = mcq_amd._lib.DeviceRun(p, abi.seeds_for(1, 4))
+    L = mcq_amd._lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bad = abi.copy_params(run.p)
+    bad.hist_stride = 101
+    assert L.mcq_run_device(C.byref(bad), run.seeds.data_ptr(), C.byref(run.out), run.ws.data_ptr(), run.ws_bytes, st) == abi.EINVAL
+    assert b"multiple of 16" in L.mcq_last_error()
+    assert L.mcq_run_device(C.byref(run.p), run.seeds.data_ptr(), C.byref(run.out), run.ws.data_ptr() + 4, run.ws_bytes - 4, st) == abi.EINVAL
+    out = abi.Outputs.from_buffer_copy(run.out)
+    out.energy_hist = run.t["energy_hist"].data_ptr() + 4
+    assert L.mcq_run_device(C.byref(run.p), run.seeds.data_ptr(), C.byref(out), run.ws.data_ptr(), run.ws_bytes, st) == abi.EINVAL
+    run.launch()  # and the well-formed call still works
+    torch.cuda.synchronize()
+    util.assert_results_equal(run.results(), oracle.run(p, abi.seeds_for(1, 4)), "after rejected calls")

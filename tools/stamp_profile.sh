@@ -12,4 +12,4 @@ if [ ! -f $LIB ] || [ $SRC -nt $LIB ]; then
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -DMCQ_STAMPS -o $LIB $SRC
 fi
 [ "$1" = "--build-only" ] && exit 0
-MCQ_DIAG_LIB=$LIB python $ROOT/bench.py --steps 1 --warmup 0 --n-steps 20000 --no-cpu-baseline "$@" > /dev/null
+MCQ_ALLOW_DIAG=1 MCQ_DIAG_LIB=$LIB python $ROOT/bench.py --steps 1 --warmup 0 --n-steps 20000 --no-cpu-baseline "$@" > /dev/null

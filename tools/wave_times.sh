@@ -12,5 +12,5 @@ if [ ! -f $LIB ] || [ $SRC -nt $LIB ]; then
 fi
 [ "$1" = "--build-only" ] && exit 0
 OUT=$1; shift
-MCQ_DIAG_LIB=$LIB MCQ_WAVE_TIMES_OUT=$OUT python $ROOT/bench.py --steps 1 --warmup 0 --n-steps 20000 --no-cpu-baseline "$@" > /dev/null
+MCQ_ALLOW_DIAG=1 MCQ_DIAG_LIB=$LIB MCQ_WAVE_TIMES_OUT=$OUT python $ROOT/bench.py --steps 1 --warmup 0 --n-steps 20000 --no-cpu-baseline "$@" > /dev/null
 python $ROOT/tools/wave_times_summary.py $OUT
