@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCQ_ABI_VERSION 2
+#define MCQ_ABI_VERSION 3
 
 /* error codes */
 #define MCQ_OK 0
@@ -99,8 +99,9 @@ typedef struct mcq_params {
     int64_t n_steps;         /* steps per chain = schedule length                    */
     int64_t n_chains;        /* n_runs (< 2^31); chain r is seeded with seeds[r] (= base_seed + r, experiments.py:508) */
     int64_t patience;        /* early_stop_patience, board only (experiments.py:349-353); < 0 = None */
-    int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1 and a multiple of 16 (HIP: rows are
-                                written in aligned 64-byte segments; energy_hist itself must be 64-byte aligned) */
+    int64_t hist_stride;     /* int32 elements per chain row of energy_hist, >= n_steps + 1, a multiple of 16 and < 2^24 (HIP: rows
+                                are written in aligned 64-byte segments; energy_hist itself must be 64-byte aligned; runs of more
+                                than 2^24 - 16 steps take trace = REDUCED or NONE) */
     int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
     int32_t lanes_per_chain; /* HIP only: 4, 8 or 16 lanes of a wavefront per chain; 0 = library default */
     int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
@@ -110,6 +111,13 @@ typedef struct mcq_params {
     int64_t n_sets;
     int64_t chains_per_set;
     const mcq_schedule* sets; /* HOST pointer (also for mcq_run_device), n_sets entries */
+    /* Optional beta(step) values, double[n_sets <= 1 ? 1 : n_sets][n_steps] (set-major): when given, the sweep uses exactly
+     * these instead of evaluating the schedule on the device.  The reference evaluates its schedules with NumPy's exp / log /
+     * cos (experiments.py:27-77), whose last bit differs between NumPy, glibc and the GPU's math library on ~0.1-5 % of the
+     * arguments; a caller that wants beta bit-identical to the reference passes the reference's own values (the Python side
+     * does: abi.host_beta_table).  mcq_run_device: DEVICE pointer; mcq_run_host: HOST pointer.  NULL: computed on the device
+     * (exact for constant / linear; the other three within 2^-51 * max(|beta_start|, |beta_end|) of the reference's value). */
+    const double* beta_table;
 } mcq_params;
 
 /*
@@ -135,7 +143,8 @@ typedef struct mcq_outputs {
      * (entry 0 = initial state): */
     int64_t* step_sum;       /* sum over chains of energy_history[e]                                   */
     int64_t* step_sumsq;     /* sum of squares                                                         */
-    int64_t* step_accepted;  /* chains whose step e - 1 was accepted (entry 0: 0)                       */
+    int64_t* step_accepted;  /* chains whose step e - 1 was accepted (entry 0: 0); includes the step at which a chain stopped
+                                early, which is executed and listed in accepted_steps but appends no entry (experiments.py:329-353) */
     int64_t* step_count;     /* chains whose history has entry e (< n_chains only after early stops)    */
 } mcq_outputs;
 
@@ -207,6 +216,8 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
 
 /* CPU restatement of the reference; host buffers; n_threads <= 1 runs chains in the calling thread. */
 int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads);
+/* the same chains with O(1) dE from per-line occupancy counters: the "best CPU" baseline of bench.py; equals mcq_oracle_run */
+int mcq_oracle_run_fast(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads);
 /* one Philox-4x32-10 block: ctr[4], key[2] -> out[4] (known-answer tests) */
 int mcq_oracle_philox_block(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
 const char* mcq_oracle_last_error(void);

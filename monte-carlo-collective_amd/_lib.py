@@ -137,6 +137,9 @@ def run_host(params, seeds, trace=True, states=True):
         raise ValueError("seeds must have one entry per chain")
     p = abi.copy_params(params)
     p.trace = abi.trace_mode(trace)
+    tab = abi.host_beta_table(p) if not p.beta_table else None  # beta as the reference's own NumPy arithmetic gives it
+    if tab is not None:
+        p.beta_table = tab.ctypes.data
     arrays = {k: np.zeros(shape, dtype=abi.OUTPUT_DTYPES[k])
               for k, shape in abi.output_shapes(p, trace=trace, states=states).items()}
     out = abi.Outputs()
@@ -172,6 +175,10 @@ class DeviceRun:
             if s.shape != (self.p.n_chains,):
                 raise ValueError("seeds must have one entry per chain")
             self.seeds = torch.from_numpy(s.view(np.int32).copy()).to(self.device)
+            tab = abi.host_beta_table(self.p) if not self.p.beta_table else None  # beta as the reference's own NumPy arithmetic gives it
+            if tab is not None:
+                self.beta = torch.from_numpy(tab).to(self.device)
+                self.p.beta_table = self.beta.data_ptr()
             self.ws_bytes = int(self.L.mcq_workspace_bytes(C.byref(self.p)))
             if self.ws_bytes == 0:
                 _check(abi.EINVAL)
@@ -227,26 +234,3 @@ class DeviceRun:
             a = t.cpu().numpy()
             res[k] = a.view(np.uint64) if abi.OUTPUT_DTYPES[k] is np.uint64 else a
         return res
-
-
-def run_many(params_list, seeds_list, trace=True, states=False):
-    """Several parameter sets at once: every set gets its own device buffers and its own HIP stream, all
-    launches are enqueued back to back and run concurrently on the GPU (a set of 8 192 chains fills only
-    a fraction of an MI355X: BASELINE configs 4 and 5 are many such sets).  Returns ([result dict], seconds)
-    with `seconds` the wall time from the first enqueue to the last completion."""
-    import time
-
-    import torch
-
-    runs = [DeviceRun(p, s, trace=trace, states=states) for p, s in zip(params_list, seeds_list)]
-    streams = [torch.cuda.Stream() for _ in runs]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # longest first (a step costs roughly N lane-operations per chain): the short sets then fill the end of the long ones
-    order = sorted(range(len(runs)), key=lambda i: -(runs[i].p.N * runs[i].p.n_steps * runs[i].p.n_chains))
-    for i in order:
-        runs[i].launch(stream=streams[i])
-    for st in streams:
-        st.synchronize()
-    secs = time.perf_counter() - t0
-    return [r.results() for r in runs], secs

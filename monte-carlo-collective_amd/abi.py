@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, EINVAL, EDEVICE, ENOMEM = 0, -1, -2, -3
 
@@ -65,6 +65,7 @@ class Params(C.Structure):
         ("n_sets", C.c_int64),
         ("chains_per_set", C.c_int64),
         ("sets", C.POINTER(Schedule)),
+        ("beta_table", C.c_void_p),
     ]
 
 
@@ -201,6 +202,7 @@ def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_
     p.n_sets, p.chains_per_set = len(sets), chains_per_set
     p.sets = C.cast(arr, C.POINTER(Schedule))
     p._sets_keepalive = arr  # the struct only holds a pointer
+    p._schedules = [dict(sp) for sp in schedule_sets]
     return p
 
 
@@ -251,7 +253,40 @@ def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="ful
     p.bits_stride = bits_stride_for(n_steps)
     p.lanes_per_chain = lanes_per_chain
     p.device = device
+    p._schedules = [dict(schedule_params)]  # what abi.beta_table evaluates (the struct itself only holds enums and doubles)
     return p
+
+
+def beta_values(schedule_params, n_steps):
+    """beta(step) for step = 0 .. n_steps - 1 exactly as the reference evaluates it (experiments.py:13-77): the same NumPy
+    functions on float64 in the same order, vectorised (NumPy's scalar and array exp / log / cos agree bit for bit).  This is
+    what the sweep is given as mcq_params.beta_table, so that beta is the reference's own value and not a second math
+    library's opinion of it."""
+    st, bc, bs, be = _check_schedule(schedule_params)
+    n = int(n_steps)
+    step = np.arange(n, dtype=np.float64)
+    if st == "constant":
+        return np.full(n, float(bc), dtype=np.float64)
+    if n <= 1:
+        return np.full(n, float(be), dtype=np.float64)
+    if st == "linear_annealing":
+        frac = step / (n - 1)
+        return bs + frac * (be - bs)
+    if st == "exponential_annealing":
+        log_ratio = np.log(be / bs)
+        t = np.clip(step, 0, n - 1) / (n - 1)
+        return bs * np.exp(log_ratio * t)
+    if st == "logarithmic_annealing":
+        log_norm = np.log(1 + n)
+        return bs + (be - bs) * (np.log(1 + np.clip(step, 0, n)) / log_norm)
+    x = (np.pi * np.clip(step, 0, n)) / n
+    return bs + ((be - bs) * (1 - np.cos(x))) / 2
+
+
+def beta_table(params, schedule_sets=None, schedule_params=None):
+    """The [n_sets][n_steps] float64 table of a Params block (beta_values per schedule)."""
+    sps = schedule_sets if schedule_sets is not None else [schedule_params]
+    return np.ascontiguousarray(np.stack([beta_values(sp, params.n_steps) for sp in sps]).reshape(len(sps), int(params.n_steps)))
 
 
 def seeds_for(base_seed, n_chains):
@@ -269,4 +304,16 @@ def copy_params(params):
     keep = getattr(params, "_sets_keepalive", None)
     if keep is not None:
         p._sets_keepalive = keep
+    for k in ("_schedules", "_beta_keepalive"):
+        if hasattr(params, k):
+            setattr(p, k, getattr(params, k))
     return p
+
+
+def host_beta_table(params):
+    """float64 [n_sets][n_steps] of a Params built by make_params / make_params_sets, or None when the schedules are not
+    known on the Python side (a hand-filled struct: the device then evaluates them itself)."""
+    sch = getattr(params, "_schedules", None)
+    if not sch or params.n_steps <= 0:
+        return None
+    return np.ascontiguousarray(np.stack([beta_values(sp, params.n_steps) for sp in sch]))

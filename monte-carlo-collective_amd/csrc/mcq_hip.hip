@@ -128,7 +128,7 @@ struct KArgs {
     float* c32_tab;         // [n_steps] (float)(-beta(step) * log2(e)): exp(-beta dE) = exp2(dE * c32)
     const uint32_t* seeds;
     mcq_outputs out;
-    unsigned long long* red;  // trace == REDUCED: [RED_STRIPES][4][red_len] per-entry sums (E, E^2, accepted, chains)
+    unsigned long long* red;  // trace == REDUCED: [RED_STRIPES][3][red_len] per-entry sums (E, E^2, accepted | chains << 32)
     long long red_len;
     unsigned long long* dbg;  // MCQ_STAMPS diagnostic build only: per-section cycle sums
 };
@@ -265,6 +265,17 @@ __global__ __launch_bounds__(256) void mcq_beta_kernel(KArgs a) {
         const double b = beta_at(a, s);
         a.beta_tab[s] = b;
         if (a.c32_tab) a.c32_tab[s] = (float)(-b * 1.4426950408889634);
+    }
+}
+
+// caller-supplied beta values (mcq_params.beta_table): copy into the workspace table and derive the float32 factor
+__global__ __launch_bounds__(256) void mcq_beta_copy_kernel(const double* __restrict__ src, double* __restrict__ beta_tab, float* __restrict__ c32_tab,
+                                                            long long n_steps) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (s < n_steps) {
+        const double b = src[s];
+        beta_tab[s] = b;
+        c32_tab[s] = (float)(-b * 1.4426950408889634);
     }
 }
 
@@ -561,6 +572,19 @@ struct Stream {
 
     // MT word `idx` of this chain: uniform base + 32-bit offset, so the address needs no 64-bit vector math
     __device__ __forceinline__ uint32_t* word(int idx) const { return (uint32_t*)(wbase + (coff + 4u * (uint32_t)idx)); }
+    // Timing experiments (tools/exp_build.sh; never defined in the shipped library, results are wrong with any of them):
+    // MCQ_EXP_HOT_LOADS / MCQ_EXP_HOT_STORES fold the block's reads / writes onto the first 64 words of the record (cache-resident),
+    // MCQ_EXP_NO_STORE drops the write-back, MCQ_EXP_NT_* mark accesses non-temporal.
+#ifdef MCQ_EXP_HOT_LOADS
+    __device__ __forceinline__ uint32_t* lword(int idx) const { return word(idx & 63); }
+#else
+    __device__ __forceinline__ uint32_t* lword(int idx) const { return word(idx); }
+#endif
+#ifdef MCQ_EXP_HOT_STORES
+    __device__ __forceinline__ uint32_t* sword(int idx) const { return word(idx & 63); }
+#else
+    __device__ __forceinline__ uint32_t* sword(int idx) const { return word(idx); }
+#endif
 
     // load the inputs of block gi: words i, i+1 and (i+397) mod 624 for the lane's WPL words.  Word 624 of the record
     // mirrors word 0 (the NEW word 0, regenerated earlier in the same pass), which is what index 624 stands for in both
@@ -571,20 +595,26 @@ struct Stream {
         const int i0 = gi + gl * WPL;
         const int ix0 = i0 + MT_M >= MT_N ? i0 + MT_M - MT_N : i0 + MT_M;
         if constexpr (WPL == 4) {
-            const uint4 q = *(const uint4*)word(i0);
+            const uint4 q = *(const uint4*)lword(i0);
             pa[0] = q.x, pa[1] = q.y, pa[2] = q.z, pa[3] = q.w;
-            const W4 x = *(const W4*)word(ix0);
+#ifdef MCQ_EXP_NT_XLOAD
+            typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const u32x4u xx = __builtin_nontemporal_load((const u32x4u*)lword(ix0));
+            px[0] = xx.x, px[1] = xx.y, px[2] = xx.z, px[3] = xx.w;
+#else
+            const W4 x = *(const W4*)lword(ix0);
             px[0] = x.x, px[1] = x.y, px[2] = x.z, px[3] = x.w;
+#endif
         } else if constexpr (WPL == 2) {
-            const uint2 q = *(const uint2*)word(i0);
+            const uint2 q = *(const uint2*)lword(i0);
             pa[0] = q.x, pa[1] = q.y;
-            const W2 x = *(const W2*)word(ix0);
+            const W2 x = *(const W2*)lword(ix0);
             px[0] = x.x, px[1] = x.y;
         } else {
-            pa[0] = *word(i0);
-            px[0] = *word(ix0);
+            pa[0] = *lword(i0);
+            px[0] = *lword(ix0);
         }
-        pn = *word(i0 + WPL);
+        pn = *lword(i0 + WPL);
         pending = true;
     }
 
@@ -646,7 +676,13 @@ struct Stream {
         uint32_t* slot = ring + so + gl * WPL;
         uint32_t* mirror = ring + (so < RING_MIRROR ? so + RING : so) + gl * WPL;  // mirror of slots 0..31 (otherwise the same store again)
         if constexpr (WPL == 4) {
-            *(uint4*)word(i0) = make_uint4(v[0], v[1], v[2], v[3]);
+#if defined(MCQ_EXP_NO_STORE)
+#elif defined(MCQ_EXP_NT_STORE)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((u32x4){v[0], v[1], v[2], v[3]}, (u32x4*)sword(i0));
+#else
+            *(uint4*)sword(i0) = make_uint4(v[0], v[1], v[2], v[3]);
+#endif
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
             *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
             // the low bytes of the four words side by side; per byte (0x80 + N - 1) - (t & maskN) keeps bit 7 iff the
@@ -732,53 +768,49 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
     return 1;
 }
 
-// LDS per chain: stage[16] | ring[64 + 32 mirrored] | board: pad, heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
+// LDS per chain: stage[16] | cold[4] | ring[64 + 32 mirrored] | board: heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
 //                full_3d: pad[full_pad], column words [Q], pad[full_pad], queens uint16 [Q]; column words are uint16 in the
 //                unrolled variants (N <= 16), uint32 otherwise
-// (the staging block sits in front of the ring so that ring[-1], which an unused draw position may address, is the chain's own)
+// (the staging block and the cold scalars sit in front of the ring: ring[-1], which an unused draw position may address -- as a
+// READ -- is one of the chain's own cold scalars)
 constexpr int LDS_STAGE = 0;                          // word offset of the energy_history staging block
-constexpr int LDS_RING = 16;                          // word offset of the ring
+constexpr int LDS_COLD = 16;                          // four per-chain scalars that change rarely: steps_to_best, n_accepted, near ties, history length
+constexpr int LDS_RING = 20;                          // word offset of the ring
 constexpr int LDS_STATE = LDS_RING + RING + RING_MIRROR;  // word offset of the state
 
-// trace == REDUCED: add the block of 16 history entries [e0, e0 + 16) of the wavefront's chains to the per-entry
-// accumulators.  A stage word is E | accepted << 31; entry e of a chain counts iff e < hist_len (chains that stopped
-// early, and the idle groups of the last wavefront, drop out by that rule).  Every lane of the wavefront takes part.
+// trace == REDUCED: add the block of 16 history entries [e0, e0 + 16) of the wavefront's chains to the per-entry accumulators.
+// A stage word is E | valid << 30 | accepted << 31: `valid` marks an appended history entry, `accepted` that the entry's step
+// was accepted.  A chain that stops early (experiments.py:349-353) leaves, at the entry it did not append, a word with the
+// accepted flag alone (the step was executed and sits in accepted_steps / rejected_steps all the same, experiments.py:329-332),
+// zeroes the rest of its block, and zeroes the whole block after every later reduction, so nothing is counted twice.
+// Lane L sums entry L & 15 over the chains of quarter L >> 4, two butterfly steps join the quarters, and lanes 0..15 issue one
+// 128-byte atomic instruction per accumulator (E, E^2, accepted | chains << 32): 3 per block of 16 steps instead of 64.
+// Every lane of the wavefront takes part.
 template <int G>
-__device__ __forceinline__ void reduce_block(const uint32_t* stage, int gl, int grp, int e0, int hist_len, unsigned long long* red,
-                                             long long red_len) {
-    constexpr int WPL = 16 / G;
+__device__ __forceinline__ void reduce_block(const uint32_t* wave_stage, int chain_lds_words, int lane, int e0, long long n_entries,
+                                             unsigned long long* red, long long red_len) {
+    constexpr int CPQ = (64 / G) / 4;  // chains per quarter of the wavefront
+    const int ent = lane & 15, q = lane >> 4;
+    uint32_t se = 0, ac = 0, cn = 0;
+    unsigned long long sq = 0;
 #pragma unroll
-    for (int w = 0; w < WPL; w++) {
-        const int idx = e0 + gl * WPL + w;
-        const uint32_t x = stage[gl * WPL + w];
-        const bool valid = idx < hist_len;
-        uint32_t se = valid ? x & 0x7fffffffu : 0u;                       // sum of E
-        unsigned long long sq = (unsigned long long)se * se;              // sum of E^2
-        uint32_t ac = valid ? (x >> 31) | 0x10000u : 0u;                  // accepted count | chains << 16
-        // over the 64 / G chains of the wavefront: inside a row of 16 lanes with DPP rotations (full rate, no LDS traffic),
-        // across the four rows with two butterfly steps
-        uint32_t sl = (uint32_t)sq, sh = (uint32_t)(sq >> 32);
-        auto ror_add = [](uint32_t v, auto ctrl) { return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
-        auto ror_add64 = [](uint32_t& lo, uint32_t& hi, auto ctrl) {
-            const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, decltype(ctrl)::value, 0xf, 0xf, false);
-            const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, decltype(ctrl)::value, 0xf, 0xf, false);
-            const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)h2 << 32) | l2);
-            lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-        };
-        if (G <= 4) se = ror_add(se, std::integral_constant<int, 0x124>()), ac = ror_add(ac, std::integral_constant<int, 0x124>()), ror_add64(sl, sh, std::integral_constant<int, 0x124>());  // row_ror:4
-        if (G <= 8) se = ror_add(se, std::integral_constant<int, 0x128>()), ac = ror_add(ac, std::integral_constant<int, 0x128>()), ror_add64(sl, sh, std::integral_constant<int, 0x128>());  // row_ror:8
-        sq = ((unsigned long long)sh << 32) | sl;
-        for (int off = 16; off < 64; off <<= 1) {
-            se += (uint32_t)__shfl_xor((int)se, off, 64);
-            ac += (uint32_t)__shfl_xor((int)ac, off, 64);
-            sq += ((unsigned long long)(uint32_t)__shfl_xor((int)(sq >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sq, off, 64);
-        }
-        if (grp == 0 && (ac >> 16) != 0) {
-            atomicAdd(red + idx, (unsigned long long)se);
-            atomicAdd(red + red_len + idx, sq);
-            atomicAdd(red + 2 * red_len + idx, (unsigned long long)(ac & 0xffffu));
-            atomicAdd(red + 3 * red_len + idx, (unsigned long long)(ac >> 16));
-        }
+    for (int c = 0; c < CPQ; c++) {
+        const uint32_t x = wave_stage[(q * CPQ + c) * chain_lds_words + ent];
+        const bool valid = (x & 0x40000000u) != 0;
+        const uint32_t e = valid ? x & 0x3fffffffu : 0u;
+        se += e, sq += (unsigned long long)e * e, ac += x >> 31, cn += valid ? 1u : 0u;
+    }
+    for (int off = 16; off < 64; off <<= 1) {
+        se += (uint32_t)__shfl_xor((int)se, off, 64);
+        ac += (uint32_t)__shfl_xor((int)ac, off, 64);
+        cn += (uint32_t)__shfl_xor((int)cn, off, 64);
+        sq += ((unsigned long long)(uint32_t)__shfl_xor((int)(sq >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sq, off, 64);
+    }
+    const long long idx = (long long)e0 + ent;
+    if (lane < 16 && idx < n_entries && (ac | cn) != 0) {
+        atomicAdd(red + idx, (unsigned long long)se);
+        atomicAdd(red + red_len + idx, sq);
+        atomicAdd(red + 2 * red_len + idx, (unsigned long long)ac | ((unsigned long long)cn << 32));
     }
 }
 
@@ -788,10 +820,10 @@ __global__ __launch_bounds__(256) void mcq_reduced_finalize_kernel(const unsigne
                                                                    long long* __restrict__ accepted, long long* __restrict__ count) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n_entries) return;
-    unsigned long long t[4] = {0, 0, 0, 0};
+    unsigned long long t[3] = {0, 0, 0};
     for (int st = 0; st < RED_STRIPES; st++)
-        for (int k = 0; k < 4; k++) t[k] += red[((long long)st * 4 + k) * red_len + e];
-    sum[e] = (long long)t[0], sumsq[e] = (long long)t[1], accepted[e] = (long long)t[2], count[e] = (long long)t[3];
+        for (int k = 0; k < 3; k++) t[k] += red[((long long)st * 3 + k) * red_len + e];
+    sum[e] = (long long)t[0], sumsq[e] = (long long)t[1], accepted[e] = (long long)(t[2] & 0xffffffffull), count[e] = (long long)(t[2] >> 32);
 }
 
 // NT > 0: ceil(N / G) is a compile-time constant, so the dE probes of a step are issued as one straight-line block
@@ -822,7 +854,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     uint32_t* base = lds + grp * a.chain_lds_words;
     uint32_t* ring = base + LDS_RING;
     uint32_t* stage = base + LDS_STAGE;
-    uint8_t* hts = (uint8_t*)(base + LDS_STATE + (N + 2) / 4);  // board (the diagonal probes read up to N-1 bytes outside either end)
+    // board: the diagonal probes read (and discard) up to N-1 bytes outside either end of the heights: in front of them lies the
+    // ring's mirror, behind them (N+2)/4 spare words -- both the chain's own
+    uint8_t* hts = (uint8_t*)(base + LDS_STATE);
     // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
     // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
     constexpr bool NARROW = MODE == MCQ_MODE_FULL3D && NT > 0;  // N <= 16: 16-bit column words
@@ -858,20 +892,37 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     if constexpr (PHILOX) rng.attach_philox(a.seeds[crow], rec[REC_POS]);
 
     int E = (int)rec[REC_E0];
-    int best = E, best_step = 0, n_acc = 0, no_imp = 0, ties = 0;
-    int hist_len = active ? (int)a.n_steps + 1 : 0;
+    int best = E, no_imp = 0;
+    // steps_to_best, n_accepted, near ties and the history length change rarely: they live in LDS, not in registers (every lane of
+    // a group performs the same read-modify-write in lockstep)
+    int* cold = (int*)(base + LDS_COLD);
+    enum { C_BEST_STEP = 0, C_N_ACC = 1, C_TIES = 2, C_HIST_LEN = 3 };
+    cold[C_BEST_STEP] = 0, cold[C_N_ACC] = 0, cold[C_TIES] = 0, cold[C_HIST_LEN] = active ? (int)a.n_steps + 1 : 0;
     unsigned long long* red = reduced ? a.red + (a.chains_per_set > 0 ? ((long long)blockIdx.x * CPW) / a.chains_per_set : 0) * a.red_set_stride +
-                                            (long long)(blockIdx.x & (RED_STRIPES - 1)) * 4 * a.red_len
+                                            (long long)(blockIdx.x & (RED_STRIPES - 1)) * 3 * a.red_len
                                       : nullptr;
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
     const bool trace = a.out.energy_hist != nullptr;
-    int32_t* hist = trace ? a.out.energy_hist + crow * a.hist_stride + gl * WPL : nullptr;
-    uint32_t* bits = a.out.accept_bits ? (uint32_t*)a.out.accept_bits + crow * a.bits_stride * 2 : nullptr;
+    // trace rows: wave-uniform address of the wavefront's first row (scalar registers) + a 32-bit byte offset per lane, so that no
+    // 64-bit pointer is held in vector registers (16 rows of hist_stride < 2^24 entries span < 2^30 bytes: checked by the host side)
+    char* const hist_base = trace ? (char*)(a.out.energy_hist + (long long)blockIdx.x * CPW * a.hist_stride) : nullptr;
+    const uint32_t hist_off = ((uint32_t)(active ? grp : 0) * (uint32_t)a.hist_stride + (uint32_t)(gl * WPL)) * 4u;
+    auto hist_at = [&](int entry) { return (int32_t*)(hist_base + (hist_off + 4u * (uint32_t)entry)); };  // this lane's WPL entries from `entry` on
+    const bool have_bits = a.out.accept_bits != nullptr;
+    char* const bits_base = have_bits ? (char*)((uint32_t*)a.out.accept_bits + (long long)blockIdx.x * CPW * a.bits_stride * 2) : nullptr;
+    const uint32_t bits_off = (uint32_t)(active ? grp : 0) * (uint32_t)a.bits_stride * 8u;
+    auto bits_at = [&](int word) { return (uint32_t*)(bits_base + (bits_off + 4u * (uint32_t)word)); };  // 32-bit word `word` of the chain's row
     const int patience = a.patience < 0 ? 0x7fffffff : (a.patience > 0x7fffffff ? 0x7fffffff : (int)a.patience);
 
-    stage[0] = (uint32_t)E;  // history entry 0 = E0 (every lane of the group writes the same word)
+    if constexpr (REDUCED) {  // stage words carry a `valid` bit (reduce_block): nothing is valid yet, idle groups never are
+#pragma unroll
+        for (int w = 0; w < WPL; w++) stage[gl * WPL + w] = 0u;
+        stage[0] = active ? (uint32_t)E | 0x40000000u : 0u;
+    } else {
+        stage[0] = (uint32_t)E;  // history entry 0 = E0 (every lane of the group writes the same word)
+    }
     if (active) {
         if (gl == 0 && a.out.initial_energy) a.out.initial_energy[chain] = E;
         if (a.out.best_state) {
@@ -1242,7 +1293,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
                 if (exact) {
                     const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
-                    acc = (r & 1) != 0, ties += r >> 1;
+                    acc = (r & 1) != 0;
+                    if (r >> 1) cold[C_TIES] += 1;
                 }
             }
 
@@ -1267,7 +1319,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 if (improved) {
                     // first index of the minimum of energy_history (experiments.py:364-365); with patience 0 the chain stops
                     // right here without appending this entry (no_imp = 0 >= 0), so the index stays
-                    if (!PATIENCE || patience > 0) best_step = e;
+                    if (!PATIENCE || patience > 0) cold[C_BEST_STEP] = e;
                     uint8_t* bo = a.out.best_state ? a.out.best_state + chain * (long long)a.state_bytes : nullptr;
                     if (bo) {
                     if (MODE == MCQ_MODE_BOARD) {
@@ -1285,22 +1337,34 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             if (PATIENCE && no_imp >= patience) {
                 // break BEFORE the append (experiments.py:349-353): entries 0..step are valid
                 active = false;
-                hist_len = e;
+                cold[C_HIST_LEN] = e;
+                if constexpr (REDUCED) {  // this step counts as executed / accepted but appends no entry; the rest of the block is stale
+#pragma unroll
+                    for (int w = 0; w < WPL; w++)
+                        if (gl * WPL + w >= (e & 15)) stage[gl * WPL + w] = gl * WPL + w == (e & 15) && acc ? 0x80000000u : 0u;
+                }
                 if (trace)
                     for (int w = 0; w < WPL; w++)
-                        if (gl * WPL + w <= (step & 15)) hist[(step & ~15) + w] = (int)stage[gl * WPL + w];
-                n_acc += __popc(accw);
-                if (bits && gl == 0) bits[step >> 5] = accw;
+                        if (gl * WPL + w <= (step & 15)) hist_at(step & ~15)[w] = (int)stage[gl * WPL + w];
+                cold[C_N_ACC] += __popc(accw);
+                if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
             } else {
-                stage[e & 15] = (uint32_t)E | (reduced && acc ? 0x80000000u : 0u);  // bit 31: this entry's step was accepted
+                stage[e & 15] = (uint32_t)E | (reduced ? (acc ? 0xC0000000u : 0x40000000u) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
                 if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
-                    if constexpr (WPL == 4) *(uint4*)(hist + e - 15) = *(const uint4*)(stage + gl * 4);
-                    else if constexpr (WPL == 2) *(uint2*)(hist + e - 15) = *(const uint2*)(stage + gl * 2);
-                    else hist[e - 15] = (int)stage[gl];
+#ifdef MCQ_EXP_NT_TRACE
+                    if constexpr (WPL == 4) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
+                    }
+#else
+                    if constexpr (WPL == 4) *(uint4*)hist_at(e - 15) = *(const uint4*)(stage + gl * 4);
+#endif
+                    else if constexpr (WPL == 2) *(uint2*)hist_at(e - 15) = *(const uint2*)(stage + gl * 2);
+                    else *hist_at(e - 15) = (int)stage[gl];
                 }
                 if ((step & 31) == 31) {
-                    n_acc += __popc(accw);  // accepted moves are counted from the bit words
-                    if (bits && gl == 0) bits[step >> 5] = accw;
+                    cold[C_N_ACC] += __popc(accw);  // accepted moves are counted from the bit words
+                    if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
                     accw = 0;
                     if ((step & 63) == 63 && a.pace) {
                         // Pacing: publish this wavefront's progress, read the row of its SIMD, and take a priority that grows with
@@ -1314,7 +1378,13 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             }
         }
         STAMP(5);  // apply + history
-        if (reduced && ((step + 1) & 15) == 15) reduce_block<G>(stage, gl, grp, (step + 1) & ~15, hist_len, red, a.red_len);
+        if (reduced && ((step + 1) & 15) == 15) {
+            reduce_block<G>(lds + LDS_STAGE, a.chain_lds_words, lane, (step + 1) & ~15, a.n_steps + 1, red, a.red_len);
+            if (!active) {  // a stopped (or idle) chain's block must not be counted again
+#pragma unroll
+                for (int w = 0; w < WPL; w++) stage[gl * WPL + w] = 0u;
+            }
+        }
         if (PATIENCE && !wave_any(active)) {
             last_entry = step + 1;
             break;
@@ -1323,24 +1393,32 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     STAMP_FLUSH(a.dbg);
     WAVE_T1(a.dbg);
     if (lane == 0 && a.pace) __hip_atomic_store(pace_row + wave_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a finished wavefront is ahead of nobody
-    if (reduced && (last_entry & 15) != 15) reduce_block<G>(stage, gl, grp, last_entry & ~15, hist_len, red, a.red_len);  // partial last block
+    if (reduced && (last_entry & 15) != 15) {  // partial last block: words behind the last entry are left from the block before
+        if (active) {
+#pragma unroll
+            for (int w = 0; w < WPL; w++)
+                if (gl * WPL + w > (last_entry & 15)) stage[gl * WPL + w] = 0u;
+        }
+        reduce_block<G>(lds + LDS_STAGE, a.chain_lds_words, lane, last_entry & ~15, a.n_steps + 1, red, a.red_len);
+    }
 
     if (active) {  // ran to n_steps: flush the partial last block and word
         if (trace && (n_steps & 15) != 15)
             for (int w = 0; w < WPL; w++)
-                if (gl * WPL + w <= (n_steps & 15)) hist[(n_steps & ~15) + w] = (int)stage[gl * WPL + w];
-        if ((n_steps & 31) != 0) n_acc += __popc(accw);
-        if (bits && gl == 0 && (n_steps & 31) != 0) bits[n_steps >> 5] = accw;
+                if (gl * WPL + w <= (n_steps & 15)) hist_at(n_steps & ~15)[w] = (int)stage[gl * WPL + w];
+        if ((n_steps & 31) != 0) cold[C_N_ACC] += __popc(accw);
+        if (have_bits && gl == 0 && (n_steps & 31) != 0) *bits_at(n_steps >> 5) = accw;
     }
     if (chain < a.n_chains) {
         if (gl == 0) {
+            const int hist_len = cold[C_HIST_LEN];
             if (a.out.hist_len) a.out.hist_len[chain] = hist_len;
             if (a.out.steps_executed) a.out.steps_executed[chain] = hist_len == n_steps + 1 ? n_steps : hist_len;
             if (a.out.best_energy) a.out.best_energy[chain] = best;
             if (a.out.final_energy) a.out.final_energy[chain] = E;
-            if (a.out.steps_to_best) a.out.steps_to_best[chain] = best_step;
-            if (a.out.n_accepted) a.out.n_accepted[chain] = n_acc;
-            if (a.out.near_ties) a.out.near_ties[chain] = ties;
+            if (a.out.steps_to_best) a.out.steps_to_best[chain] = cold[C_BEST_STEP];
+            if (a.out.n_accepted) a.out.n_accepted[chain] = cold[C_N_ACC];
+            if (a.out.near_ties) a.out.near_ties[chain] = cold[C_TIES];
         }
         if (a.out.final_state) {
             uint8_t* fo = a.out.final_state + chain * (long long)a.state_bytes;
@@ -1480,7 +1558,7 @@ size_t tab_stride_for(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p
 size_t beta_tab_bytes(const mcq_params* p) { return n_sets_of(p) * tab_stride_for(p) * 8; }
 size_t c32_tab_bytes(const mcq_params* p) { return n_sets_of(p) * tab_stride_for(p) * 4; }
 long long red_len_for(const mcq_params* p) { return (p->n_steps + 1 + 31) & ~31LL; }
-size_t red_set_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 4 * red_len_for(p) * 8 : 0; }
+size_t red_set_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 3 * red_len_for(p) * 8 : 0; }
 size_t red_bytes(const mcq_params* p) { return n_sets_of(p) * red_set_bytes(p); }
 constexpr size_t PACE_BYTES = 2048 * 16 * 4;  // 8 XCC x 4 SE x 16 CU x 4 SIMD rows of 16 wave slots
 
@@ -1489,9 +1567,14 @@ constexpr size_t PACE_BYTES = 2048 * 16 * 4;  // 8 XCC x 4 SE x 16 CU x 4 SIMD r
 int chain_lds_words_for(int N, int mode, bool narrow) {
     const int Q = N * N, pad = (N + 3) & ~3;
     int w = LDS_STATE;
-    if (mode == MCQ_MODE_BOARD) w += 2 * ((N + 2) / 4) + (Q + 3) / 4;
+    if (mode == MCQ_MODE_BOARD) w += (Q + 3) / 4 + (N + 2) / 4;
     else w += (narrow ? (2 * pad + Q + 1) / 2 : 2 * pad + Q) + (Q + 1) / 2;
-    return (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
+    w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
+    // The chains of a wavefront make many accesses at the SAME offset of their slices (history staging, cold scalars, ring appends):
+    // a stride of 4 mod 8 words puts the 8 chains of a 32-lane access group on 8 different banks; 0 mod 8 would serialise them
+    // (measured on the headline problem: stride 160 words 142.4 ms, 156 words 134.3 ms).
+    if (w % 8 == 0) w += 4;
+    return w;
 }
 
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
@@ -1588,6 +1671,11 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
     if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
         if constexpr (G == 8) {  // N <= 16: 16-bit column words, four lanes around each of the two cells
             const int nt = (a.N + 3) / 4;
+            if (a.red && nt == 3) {  // BASELINE config 3's shape with the reduced trace
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+                return launch_sweep<MODE, G, false, 3, true>(b, s);
+            }
             if (!a.red && nt <= 4) {
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
@@ -1624,6 +1712,8 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 }
         }
         if constexpr (G == 8) {  // larger boards run 8 lanes per chain by default: 3 or 4 straight-line probe passes
+            if (!pat && a.red && a.N > 16 && a.N <= 24) return launch_sweep<MODE, G, false, 3, true>(a, s);  // the beta-pair driver's shape (N = 24, reduced trace)
+            if (!pat && a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, false, 2, true>(a, s);
             if (!pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
             if (!pat && !a.red && a.N > 8) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
             if (pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, true, 3, false>(a, s) : launch_sweep<MODE, G, true, 4, false>(a, s);
@@ -1642,7 +1732,7 @@ int launch_sweep_mode(const KArgs& a, int G, hipStream_t s) {
 }
 
 int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
-                    size_t workspace_bytes, void* hip_stream, hipEvent_t* ev) {
+                    size_t workspace_bytes, void* hip_stream, hipEvent_t* ev, const double* beta_table_dev) {
     int rc = validate(p);
     if (rc != MCQ_OK) return rc;
     if (!seeds || !out || !workspace) return fail(MCQ_EINVAL, "null argument");
@@ -1653,6 +1743,8 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         if (!out->energy_hist || !out->accept_bits) return fail(MCQ_EINVAL, "trace requested without buffers");
         if (p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
         if (p->hist_stride % 16 != 0) return fail(MCQ_EINVAL, "hist_stride must be a multiple of 16");
+        if (p->hist_stride >= (1LL << 24) || p->bits_stride >= (1LL << 24))
+            return fail(MCQ_EINVAL, "a full trace takes at most 2^24 - 16 entries per chain; use trace = reduced (or none) for longer runs");
         if (((uintptr_t)out->energy_hist & 63u) != 0) return fail(MCQ_EINVAL, "energy_hist must be 64-byte aligned");
         if (p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
     }
@@ -1689,7 +1781,11 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
             KArgs b = a;
             if (p->n_sets > 1) b.sched = p->sets[t].sched, b.beta_const = p->sets[t].beta_const, b.beta_start = p->sets[t].beta_start, b.beta_end = p->sets[t].beta_end;
             b.beta_tab = a.beta_tab + t * a.tab_stride, b.c32_tab = a.c32_tab + t * a.tab_stride;
-            hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, b);
+            if (beta_table_dev)
+                hipLaunchKernelGGL(mcq_beta_copy_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s,
+                                   beta_table_dev + t * (size_t)p->n_steps, b.beta_tab, b.c32_tab, (long long)p->n_steps);
+            else
+                hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, b);
         }
     }
     hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
@@ -1743,7 +1839,7 @@ size_t mcq_workspace_bytes(const mcq_params* p) {
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
                    size_t workspace_bytes, void* hip_stream) {
-    return run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, nullptr);
+    return run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, nullptr, p ? p->beta_table : nullptr);
 }
 
 int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -1766,7 +1862,7 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, wt_waves * 32));
     HIP_TRY(hipMemset(g_dbg, 0, wt_waves * 32));
 #endif
-    int rc = run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, ev);
+    int rc = run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, ev, p ? p->beta_table : nullptr);
 #ifdef MCQ_STAMPS
     if (rc == MCQ_OK) {
         unsigned long long h[8];
@@ -1860,7 +1956,7 @@ int mcq_beta_table_device(const mcq_params* p, double* beta_out, float* c32_out,
         else a.sched = p->sched, a.beta_const = p->beta_const, a.beta_start = p->beta_start, a.beta_end = p->beta_end;
         a.beta_tab = beta_out + t * (size_t)p->n_steps;
         a.c32_tab = c32_out ? c32_out + t * (size_t)p->n_steps : nullptr;
-        hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, a);  // always the device's own evaluation
     }
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
@@ -1903,12 +1999,14 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
     };
     uint32_t* d_seeds = nullptr;
     void* d_ws = nullptr;
+    double* d_beta = nullptr;
     const size_t ws_bytes = mcq_workspace_bytes(p);
     auto cleanup = [&]() {
         for (auto& b : bufs)
             if (*b.dev) (void)hipFree(*b.dev);
         if (d_seeds) (void)hipFree(d_seeds);
         if (d_ws) (void)hipFree(d_ws);
+        if (d_beta) (void)hipFree(d_beta);
     };
 #define HOST_TRY(expr)                                                                                              \
     do {                                                                                                            \
@@ -1923,8 +2021,15 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
     HOST_TRY(hipMalloc((void**)&d_seeds, n * 4));
     HOST_TRY(hipMalloc(&d_ws, ws_bytes));
     HOST_TRY(hipMemcpy(d_seeds, seeds, n * 4, hipMemcpyHostToDevice));
+    mcq_params pd = *p;
+    if (p->beta_table && p->n_steps > 0) {  // the host table goes to the device
+        const size_t tb = n_sets_of(p) * (size_t)p->n_steps * 8;
+        HOST_TRY(hipMalloc((void**)&d_beta, tb));
+        HOST_TRY(hipMemcpy(d_beta, p->beta_table, tb, hipMemcpyHostToDevice));
+    }
+    pd.beta_table = d_beta;
     float i_ms = 0.f, s_ms = 0.f;
-    rc = mcq_run_device_timed(p, d_seeds, &d, d_ws, ws_bytes, nullptr, &i_ms, &s_ms);
+    rc = mcq_run_device_timed(&pd, d_seeds, &d, d_ws, ws_bytes, nullptr, &i_ms, &s_ms);
     if (rc != MCQ_OK) {
         cleanup();
         return rc;

@@ -6,55 +6,57 @@ Same names, arguments, seed derivations, labels and result dicts as the referenc
     measure_min_energy_vs_N    experiments.py:1031-1201 seed = base_seed + 10*idx + sum(ord(c)) % 1000 (1060-1067)
     main / load_config         experiments.py:1204-1391 config.yaml dispatch
 
-Plotting is out of scope; with plot=True the drivers write the reference's CSV data
-products (results/*.csv: per-step mean/std energy, binned acceptance rates, min energy and
-steps-to-best per N) and no PNGs.  The reference's run_compare_beta_end raises TypeError after all
-compute when plot=True (it passes annealing_type= / init_mode= to a plot function that lacks them,
-experiments.py:1020-1021 vs 848); that bug is not reproduced.
+Every driver turns its loop into a job list and hands it to jobs.JobSet: all jobs run device-resident and
+concurrently, the chains of each job sharded over the ranks of `dist` (torch.distributed, one process per GPU), and ONE
+packed all-reduce brings the per-pair / per-cell minima, counters, per-run best energies and -- where CSVs are written
+-- the per-step integer sums to every rank.  Rank 0 writes the files.
 
-Every driver takes `runner=`: a callable with run_chains' signature.  The default is the GPU path;
-tests inject the CPU oracle to check the host logic without a GPU.
+Histories.  The reference returns every energy history to the caller (experiments.py:573, 843-846).  That is kept for
+runs whose traces are small (`histories=True`, or "auto" below HISTORY_BYTES_AUTO in a single process); beyond that the
+drivers run with trace = REDUCED: `all_histories[label]` is None and the per-step mean / std and binned acceptance come
+from on-device integer sums ("energy_stats" / "acceptance" in the result), which is all the reference's plot functions
+consume (experiments.py:593-608, 660-711).  BASELINE config 5 (16 pairs x 8 192 chains x 10^5 steps) would otherwise be
+52 GB of trace.
+
+Plotting is out of scope; with plot=True the drivers write the reference's CSV data products
+(results/*.csv) and no PNGs.  The reference's run_compare_beta_end raises TypeError after all compute when plot=True
+(experiments.py:1020-1021 vs 848); that bug is not reproduced.
+
+Every driver takes `runner=`: a callable with run_chains' signature.  The default is the GPU path; tests inject the CPU
+oracle to check the host logic without a GPU.
 """
 import os
 
 import numpy as np
 
+from . import distributed as dm
 from . import experiments as ex
+from . import jobs as jb
+from .jobs import acceptance_bins_from_steps, mean_std_from_sums  # noqa: F401  (re-exported: the CSV arithmetic)
+
+HISTORY_BYTES_AUTO = 256 << 20  # "auto": full histories come back to the host below this many bytes of trace
 
 
 def _runner_or_default(runner):
     return ex.run_chains if runner is None else runner
 
 
-def _run_all(runner, jobs, trace):
-    """Every job of a driver (one per beta pair / per (init_mode, N) cell).  On the GPU path the jobs are launched
-    concurrently on separate streams; an injected runner gets them one by one."""
-    prepared = []
-    for (N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience) in jobs:
-        if n_runs > 1:
-            if sp is None:
-                raise ValueError("schedule_params is required for parallel execution when n_runs > 1")
-        else:
-            patience = None  # the n_runs == 1 branch does not forward early_stop_patience (experiments.py:550-558)
-        prepared.append(dict(N=N, n_steps=n_steps, init_mode=init_mode, schedule_params=sp, seeds=ex.abi.seeds_for(base_seed, n_runs),
-                             mcmc_type=mcmc_type, early_stop_patience=patience))
-    if runner is None:
-        return ex.run_chains_many(prepared, trace=trace)[0]
-    return [runner(j["N"], j["n_steps"], j["init_mode"], j["schedule_params"], j["seeds"], mcmc_type=j["mcmc_type"],
-                   early_stop_patience=j["early_stop_patience"], trace=trace)[0] for j in prepared]
+def _want(histories, jobs, dist, need_steps):
+    """`histories` in (True, False, "auto") -> jobs.JobSet's `want`."""
+    if histories == "auto":
+        total = sum(j["n_runs"] * (j["n_steps"] + 1) * 4 for j in jobs)
+        histories = dm.rank_world(dist)[1] == 1 and total <= HISTORY_BYTES_AUTO
+    if histories:
+        return "histories"
+    return "stats" if need_steps else "summary"
 
 
-def _run(runner, N, n_steps, init_mode, schedule_params, n_runs, base_seed, mcmc_type, early_stop_patience, trace):
-    """run_experiment's semantics (experiments.py:475-573) on an arbitrary runner; returns the raw result dict."""
-    if n_runs > 1:
-        if schedule_params is None:
-            raise ValueError("schedule_params is required for parallel execution when n_runs > 1")
-        patience = early_stop_patience
-    else:
-        patience = None  # the n_runs == 1 branch does not forward early_stop_patience (experiments.py:550-558)
-    seeds = ex.abi.seeds_for(base_seed, n_runs)
-    res, _ = runner(N, n_steps, init_mode, schedule_params, seeds, mcmc_type=mcmc_type, early_stop_patience=patience, trace=trace)
-    return res
+def _is_writer(dist):
+    return dm.rank_world(dist)[0] == 0
+
+
+def _histories_of(res):
+    return [res["energy_hist"][r, : int(res["hist_len"][r])] for r in range(len(res["hist_len"]))]
 
 
 def energy_statistics(all_histories):
@@ -67,20 +69,6 @@ def energy_statistics(all_histories):
     return e.mean(axis=0), e.std(axis=0)
 
 
-def mean_std_from_sums(step_sum, step_sumsq, step_count):
-    """Per-step mean and population std from integer sums (the on-device statistics of a resident trace).
-    The mean equals np.mean of the int64 matrix bit for bit (all partial sums are exact in float64); the
-    std is computed from the exact integer numerator n*sum(x^2) - sum(x)^2 and agrees with NumPy's two-pass
-    formula to ~1e-15 relative."""
-    s = np.asarray(step_sum, dtype=np.int64)
-    q = np.asarray(step_sumsq, dtype=np.int64)
-    n = np.asarray(step_count, dtype=np.int64)
-    mean = s / n
-    num = np.array([int(ni) * int(qi) - int(si) * int(si) for ni, qi, si in zip(n, q, s)], dtype=object)
-    var = np.array([float(v) / (int(ni) * int(ni)) for v, ni in zip(num, n)], dtype=np.float64)
-    return mean, np.sqrt(np.maximum(var, 0.0))
-
-
 def acceptance_rates_from_bins(bin_accepted, bin_proposed):
     """Rates per bin from the on-device counts; empty bins are NaN like the reference (experiments.py:690-693)."""
     a = np.asarray(bin_accepted, dtype=np.float64)
@@ -89,9 +77,10 @@ def acceptance_rates_from_bins(bin_accepted, bin_proposed):
         return np.where(p > 0, a / p, np.nan)
 
 
-def write_energy_csv(all_histories, label, out_dir="results"):
-    """results/{label}.csv with columns step, mean_energy, std_energy (experiments.py:600-608)."""
-    mean, std = energy_statistics(all_histories)
+def write_energy_csv(all_histories, label, out_dir="results", stats=None):
+    """results/{label}.csv with columns step, mean_energy, std_energy (experiments.py:600-608); `stats` = (mean, std) from
+    the on-device sums when the histories never left the GPU."""
+    mean, std = energy_statistics(all_histories) if stats is None else stats
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{label}.csv")
     np.savetxt(path, np.column_stack([np.arange(len(mean)), mean, std]), delimiter=",", header="step,mean_energy,std_energy",
@@ -130,58 +119,71 @@ def write_acceptance_csv(centers, rates, label, out_dir="results"):
 
 def run_beta_start_end_pairs(N, n_steps, beta_start_ends, annealing_type="linear_annealing", init_mode="random", n_runs=5,
                              base_seed=0, verbose=True, plot=True, out_path=None, out_path_acceptance=None,
-                             mcmc_type="full_3d", early_stop_patience=100000, runner=None):
-    """experiments.py:741-846.  Returns {"all_histories": {label: [...]}, "all_best_energies": {label: [...]}}
-    with label f"beta: {beta_start}->{beta_end}" (806)."""
-    all_histories, all_best, all_acc, all_rej = {}, {}, {}, {}
+                             mcmc_type="full_3d", early_stop_patience=100000, runner=None, dist=None, histories="auto",
+                             csv_prefix=""):
+    """experiments.py:741-846.  Returns {"all_histories": {label: [...] or None}, "all_best_energies": {label: [...]}} with
+    label f"beta: {beta_start}->{beta_end}" (806), plus "min_energies" {label: min}, and -- when the histories stay on the
+    device -- "energy_stats" {label: (mean, std)} and "acceptance" {label: (centers, rates)}.  The pairs run as one launch
+    with one schedule set per pair; with `dist` every pair's chains are sharded over the ranks."""
     jobs, labels = [], []
     for idx, (beta_start, beta_end) in enumerate(beta_start_ends):
         sp = {"type": annealing_type, "beta_start": beta_start, "beta_end": beta_end}
         ex.build_schedule_from_params(annealing_type, n_steps, beta_start=beta_start, beta_end=beta_end)  # the reference's ValueErrors
-        jobs.append((N, n_steps, init_mode, sp, n_runs, base_seed + idx * 1000, mcmc_type, early_stop_patience))
+        jobs.append(jb.make_job(N, n_steps, init_mode, sp, n_runs, base_seed + idx * 1000, mcmc_type, early_stop_patience))
         labels.append(f"beta: {beta_start}->{beta_end}")
-    for label, res in zip(labels, _run_all(runner, jobs, True)):
-        all_histories[label] = [res["energy_hist"][r, : int(res["hist_len"][r])] for r in range(n_runs)]
+    want = _want(histories, jobs, dist, need_steps=plot)
+    results = jb.JobSet(jobs, want=want, dist=dist, runner=runner).run()
+    all_histories, all_best, mins, stats, acceptance = {}, {}, {}, {}, {}
+    for label, res in zip(labels, results):
         all_best[label] = [int(b) for b in res["best_energy"]]
-        if plot and out_path_acceptance is not None:
-            steps = [ex.accepted_rejected_steps(res, r) for r in range(n_runs)]
-            all_acc[label], all_rej[label] = [s[0] for s in steps], [s[1] for s in steps]
+        mins[label] = res["summary"]["min_best"]
+        if want == "histories":
+            all_histories[label] = _histories_of(res)
+            if plot and out_path_acceptance is not None:
+                steps = [ex.accepted_rejected_steps(res, r) for r in range(n_runs)]
+                acceptance[label] = acceptance_rates_binned([s[0] for s in steps], [s[1] for s in steps], n_steps, n_bins=100)
+        else:
+            all_histories[label] = None
+            if want == "stats":
+                stats[label] = mean_std_from_sums(res["step_sum"], res["step_sumsq"], res["step_count"])
+                acceptance[label] = acceptance_bins_from_steps(res["step_accepted"], res["step_count"], res["step_stopped"], n_steps, n_bins=100)[:2]
         if verbose:
             for e in all_best[label]:
                 print(e)
             print(np.mean(all_best[label]))
-    if plot:
-        for label, hist in all_histories.items():
-            write_energy_csv(hist, label)
+    if plot and _is_writer(dist):
+        for label in labels:
+            write_energy_csv(all_histories[label], csv_prefix + label, stats=stats.get(label))
         if out_path_acceptance is not None:
-            for label in all_histories:
-                c, r = acceptance_rates_binned(all_acc[label], all_rej[label], n_steps, n_bins=100)
-                write_acceptance_csv(c, r, label)
-    return {"all_histories": all_histories, "all_best_energies": all_best}
+            for label in labels:
+                write_acceptance_csv(*acceptance[label], csv_prefix + label)
+    out = {"all_histories": all_histories, "all_best_energies": all_best, "min_energies": mins}
+    if stats:
+        out["energy_stats"] = stats
+    if acceptance:
+        out["acceptance"] = acceptance
+    return out
 
 
 def run_compare_beta_end(Ns, n_steps, beta_start_ends, annealing_type="linear_annealing", init_mode="random", n_runs=5,
                          base_seed=0, verbose=True, plot=True, out_path=None, mcmc_type="full_3d",
-                         early_stop_patience=100000, runner=None):
+                         early_stop_patience=100000, runner=None, dist=None, histories="auto"):
     """experiments.py:943-1029: the pair experiment for two board sizes, the second at base_seed + 10000."""
     if len(Ns) != 2:
         raise ValueError("Ns must contain exactly 2 values")
     kw = dict(n_steps=n_steps, beta_start_ends=beta_start_ends, annealing_type=annealing_type, init_mode=init_mode,
-              n_runs=n_runs, verbose=verbose, plot=False, out_path=None, out_path_acceptance=None, mcmc_type=mcmc_type,
-              early_stop_patience=early_stop_patience, runner=runner)
-    r1 = run_beta_start_end_pairs(N=Ns[0], base_seed=base_seed, **kw)
-    r2 = run_beta_start_end_pairs(N=Ns[1], base_seed=base_seed + 10000, **kw)
-    if plot:
-        for N, r in ((Ns[0], r1), (Ns[1], r2)):
-            for label, hist in r["all_histories"].items():
-                write_energy_csv(hist, f"N{N}_{label}")
+              n_runs=n_runs, verbose=verbose, plot=plot, out_path=None, out_path_acceptance=None, mcmc_type=mcmc_type,
+              early_stop_patience=early_stop_patience, runner=runner, dist=dist, histories=histories)
+    r1 = run_beta_start_end_pairs(N=Ns[0], base_seed=base_seed, csv_prefix=f"N{Ns[0]}_", **kw)
+    r2 = run_beta_start_end_pairs(N=Ns[1], base_seed=base_seed + 10000, csv_prefix=f"N{Ns[1]}_", **kw)
     return {"N1": Ns[0], "N2": Ns[1], "result_N1": r1, "result_N2": r2}
 
 
 def measure_min_energy_vs_N(Ns, n_steps, beta_schedule, schedule_params=None, init_modes=["random"], n_runs=5, base_seed=100,
                             verbose=True, plot=True, out_path=None, mcmc_type="full_3d", early_stop_patience=100000,
-                            runner=None):
-    """experiments.py:1031-1201.  Histories are discarded by this experiment (1061), so no trace is produced."""
+                            runner=None, dist=None):
+    """experiments.py:1031-1201.  Histories are discarded by this experiment (1061), so no trace is produced: every
+    (init_mode, N) cell is a launch of its own stream, all cells run concurrently, each cell's chains sharded over `dist`."""
     if isinstance(init_modes, str):
         init_modes = [init_modes]
     if schedule_params is None:
@@ -190,8 +192,8 @@ def measure_min_energy_vs_N(Ns, n_steps, beta_schedule, schedule_params=None, in
     for init_mode in init_modes:
         offset = sum(ord(c) for c in init_mode) % 1000
         for idx, N in enumerate(Ns):
-            jobs.append((N, n_steps, init_mode, schedule_params, n_runs, base_seed + 10 * idx + offset, mcmc_type, early_stop_patience))
-    all_res = iter(_run_all(runner, jobs, False))
+            jobs.append(jb.make_job(N, n_steps, init_mode, schedule_params, n_runs, base_seed + 10 * idx + offset, mcmc_type, early_stop_patience))
+    all_res = iter(jb.JobSet(jobs, want="summary", dist=dist, runner=runner).run())
     results = {}
     for init_mode in init_modes:
         all_min, all_stb = [], []
@@ -209,7 +211,7 @@ def measure_min_energy_vs_N(Ns, n_steps, beta_schedule, schedule_params=None, in
             "std_steps_to_best": np.array([s.std() for s in all_stb]),
             "all_steps_to_best": all_stb,
         }
-    if plot:
+    if plot and _is_writer(dist):
         os.makedirs("results", exist_ok=True)
         for init_mode in init_modes:
             r = results[init_mode]
@@ -262,7 +264,20 @@ def load_config(path="config.yaml"):
         return yaml.safe_load(f)
 
 
-def main(config="config.yaml", runner=None):
+def _single_N(N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience, label, runner, dist, histories):
+    """One run_experiment + plot_energy_histories (experiments.py:1237-1256): returns (histories or None, best energies)
+    and writes results/{label}.csv from the histories or, for large runs, from the on-device sums."""
+    job = jb.make_job(N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience)
+    want = _want(histories, [job], dist, need_steps=True)
+    (res,) = jb.JobSet([job], want=want, dist=dist, runner=runner).run()
+    hist = _histories_of(res) if want == "histories" else None
+    stats = None if hist is not None else mean_std_from_sums(res["step_sum"], res["step_sumsq"], res["step_count"])
+    if _is_writer(dist):
+        write_energy_csv(hist, label, stats=stats)
+    return hist, [int(b) for b in res["best_energy"]]
+
+
+def main(config="config.yaml", runner=None, dist=None, histories="auto"):
     """The reference's __main__ dispatch (experiments.py:1204-1391) without the plots; returns the result object."""
     cfg = load_config(config) if isinstance(config, str) else config
     et = cfg["experiment_type"]
@@ -272,29 +287,23 @@ def main(config="config.yaml", runner=None):
     patience = common.get("early_stop_patience", 100000)
     if patience == "None":  # `early_stop_patience: None` parses as a string (experiments.py:1217-1218)
         patience = None
-    run = _runner_or_default(runner)
     if et == "single_N":
         N = cfg["single_N"]["N"]
         sched_cfg = common["betta_scheduling"]
         if isinstance(sched_cfg["type"], list):
             out = {}
             for _sched, base_seed, _desc, label, sp in ex.build_schedules_from_types(sched_cfg["type"], sched_cfg, n_steps):
-                res = _run(run, N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience, True)
-                out[label] = ([res["energy_hist"][r, : int(res["hist_len"][r])] for r in range(n_runs)], [int(b) for b in res["best_energy"]])
-                write_energy_csv(out[label][0], label)
+                out[label] = _single_N(N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience, label, runner, dist, histories)
             return out
         _sched, base_seed, _desc, sp = ex.build_schedule_from_common(common, n_steps)
-        res = _run(run, N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience, True)
-        hist = [res["energy_hist"][r, : int(res["hist_len"][r])] for r in range(n_runs)]
-        write_energy_csv(hist, "Schedule")
-        return hist, [int(b) for b in res["best_energy"]]
+        return _single_N(N, n_steps, init_mode, sp, n_runs, base_seed, mcmc_type, patience, "Schedule", runner, dist, histories)
     if et == "measure_min_energy_vs_N":
         params = cfg["measure_min_energy_vs_N"]
         sched, base_seed, _desc, sp = ex.build_schedule_from_common(common, n_steps)
         modes = params.get("init_modes", [init_mode])
         return measure_min_energy_vs_N(params["Ns"], n_steps, sched, schedule_params=sp, init_modes=modes, n_runs=n_runs,
                                        base_seed=base_seed, verbose=verbose, plot=True, out_path=common["output_path"],
-                                       mcmc_type=mcmc_type, early_stop_patience=patience, runner=runner)
+                                       mcmc_type=mcmc_type, early_stop_patience=patience, runner=runner, dist=dist)
     if et == "beta_start_end_pairs":
         params = cfg["beta_start_end_pairs"]
         return run_beta_start_end_pairs(params["N"], n_steps, params["beta_start_ends"],
@@ -302,12 +311,12 @@ def main(config="config.yaml", runner=None):
                                         n_runs=n_runs, base_seed=common["betta_scheduling"].get("base_seed", 0), verbose=verbose,
                                         plot=True, out_path=params.get("output_path", common["output_path"]),
                                         out_path_acceptance=params.get("output_path_acceptance"), mcmc_type=mcmc_type,
-                                        early_stop_patience=patience, runner=runner)
+                                        early_stop_patience=patience, runner=runner, dist=dist, histories=histories)
     if et == "compare_beta_end":
         params = cfg["compare_beta_end"]
         return run_compare_beta_end(params["Ns"], n_steps, params["beta_start_ends"],
                                     annealing_type=params.get("annealing_type", "linear_annealing"), init_mode=init_mode,
                                     n_runs=n_runs, base_seed=common["betta_scheduling"].get("base_seed", 0), verbose=verbose,
                                     plot=True, out_path=params.get("output_path"), mcmc_type=mcmc_type,
-                                    early_stop_patience=patience, runner=runner)
+                                    early_stop_patience=patience, runner=runner, dist=dist, histories=histories)
     raise ValueError(f"Unknown experiment_type: {et}")

@@ -175,55 +175,6 @@ def run_chains(N, n_steps, init_mode, schedule_params, seeds, mcmc_type="full_3d
     return _lib.run_host(params, seeds.astype(np.uint32), trace=trace, states=states)
 
 
-def _run_batched(jobs, trace, states):
-    """Jobs that differ only in their beta schedule and seeds (run_beta_start_end_pairs' pairs, experiments.py:741-846)
-    run as ONE launch with one schedule set per job (mcq_params.sets): the sweep then fills the device, and paces
-    itself, as a whole.  Chain counts that are not a multiple of 16 are padded with copies of the job's first chain,
-    whose results are dropped.  Returns None when the jobs cannot be batched."""
-    if len(jobs) < 2:
-        return None
-    key = lambda j: (j["N"], j["n_steps"], j["init_mode"], j.get("mcmc_type", "full_3d"), j.get("early_stop_patience"),
-                     j.get("lanes_per_chain", 0), len(j["seeds"]))
-    if len({key(j) for j in jobs}) != 1 or any(j["schedule_params"] is None for j in jobs):
-        return None
-    n = len(jobs[0]["seeds"])
-    cps = (n + 15) // 16 * 16
-    if n == 0 or (cps != n and trace == "reduced"):  # padded chains would enter the per-step sums
-        return None
-    seeds = []
-    for j in jobs:
-        sd = np.asarray(j["seeds"])
-        if sd.min() < 0 or sd.max() > 2**32 - 1:
-            raise ValueError("Seed must be between 0 and 2**32 - 1")
-        seeds.append(np.concatenate([sd, np.full(cps - n, sd[0])]).astype(np.uint32))
-    j0 = jobs[0]
-    params = abi.make_params_sets(j0["N"], j0["n_steps"], j0["init_mode"], [j["schedule_params"] for j in jobs], cps,
-                                  mcmc_type=j0.get("mcmc_type", "full_3d"), early_stop_patience=j0.get("early_stop_patience"),
-                                  trace=trace, lanes_per_chain=j0.get("lanes_per_chain", 0))
-    res, secs = _lib.run_host(params, np.concatenate(seeds), trace=trace, states=states)
-    per_set = ("step_sum", "step_sumsq", "step_accepted", "step_count")
-    return [{k: (v[t] if k in per_set else v[t * cps:t * cps + n]) for k, v in res.items()} for t in range(len(jobs))], secs
-
-
-def run_chains_many(jobs, trace=True, states=False):
-    """Concurrent form of run_chains: `jobs` is a list of dicts with run_chains' arguments (N, n_steps, init_mode,
-    schedule_params, seeds, mcmc_type, early_stop_patience).  All jobs are enqueued on their own streams and
-    overlap on the GPU.  Returns ([result dict per job], seconds)."""
-    batched = _run_batched(jobs, trace, states)
-    if batched is not None:
-        return batched
-    plist, slist = [], []
-    for j in jobs:
-        seeds = np.asarray(j["seeds"])
-        if seeds.size and (seeds.min() < 0 or seeds.max() > 2**32 - 1):
-            raise ValueError("Seed must be between 0 and 2**32 - 1")
-        plist.append(abi.make_params(j["N"], j["n_steps"], j["init_mode"], j["schedule_params"], len(seeds),
-                                     mcmc_type=j.get("mcmc_type", "full_3d"), early_stop_patience=j.get("early_stop_patience"),
-                                     trace=trace, lanes_per_chain=j.get("lanes_per_chain", 0)))
-        slist.append(seeds.astype(np.uint32))
-    return _lib.run_many(plist, slist, trace=trace, states=states)
-
-
 def accepted_rejected_steps(res, r):
     """Step indices of accepted / rejected proposals of chain r (experiments.py:329-332)."""
     n = int(res["steps_executed"][r])

@@ -172,6 +172,7 @@ int mcq_oracle_rng_stream(uint32_t seed, int kind, uint32_t arg, int64_t n, uint
  * order; the file is compiled with -ffp-contract=off so no product-sum is fused.
  * ---------------------------------------------------------------------------------------- */
 static double beta_at(const mcq_params* p, int64_t step) {
+    if (p->beta_table) return p->beta_table[step]; /* the reference's own values (abi.beta_values: NumPy, like experiments.py:13-77) */
     const double bs = p->beta_start, be = p->beta_end;
     const int64_t n = p->n_steps;
     switch (p->sched) {
@@ -205,6 +206,9 @@ static double beta_at(const mcq_params* p, int64_t step) {
 }
 
 int mcq_oracle_beta_table(const mcq_params* p, const int64_t* steps, int64_t n, double* out) {
+    mcq_params q = *p;
+    q.beta_table = NULL; /* always the oracle's own libm evaluation */
+    p = &q;
     for (int64_t t = 0; t < n; t++) out[t] = beta_at(p, steps[t]);
     return 0;
 }
@@ -293,6 +297,7 @@ typedef struct {
     const mcq_params* p;
     const uint32_t* seeds;
     const mcq_outputs* out;
+    int fast; /* 0: the reference's O(N^2) scan; 1: line counters (mcq_oracle_run_fast) */
 } job_t;
 
 static int64_t ulp_distance(double a, double b) {
@@ -571,6 +576,239 @@ static int run_full_chain(const job_t* jb, int64_t r) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * "Best CPU" variant (SURVEY 8d's second baseline; bench.py's cpu_baseline.fast_port): the same chains with O(1) dE from
+ * per-line occupancy counters instead of the reference's O(N^2) scan.  Two distinct cells attack iff they share one of the
+ * 13 lines through a cell, and share at most one, so conflicts(cell) = sum over the 13 families of the queens on the cell's
+ * line of that family, minus the moving queen where it is counted.  Families (D = 2N - 1):
+ *   0 (j,k)  1 (i,k)  2 (i,j)                                                    axes          N^2 lines each
+ *   3 (k,i-j) 4 (k,i+j)  5 (j,i-k) 6 (j,i+k)  7 (i,j-k) 8 (i,j+k)               plane diagonals  N D each
+ *   9 (i-j,i-k) 10 (i-j,i+k) 11 (i+j,i-k) 12 (i+j,i+k)                          space diagonals  D^2 each
+ * Results must equal mcq_oracle_run's bit for bit (tests/test_oracle_fast.py): same stream, same draws, same floats.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int N, D;
+    int base[13];
+    uint8_t* cnt;
+} lines_t;
+
+static size_t lines_total(int N) {
+    const size_t D = 2 * (size_t)N - 1, Q = (size_t)N * N;
+    return 3 * Q + 6 * N * D + 4 * D * D;
+}
+
+static void lines_setup(lines_t* L, int N, uint8_t* cnt) {
+    const int D = 2 * N - 1, Q = N * N;
+    L->N = N, L->D = D, L->cnt = cnt;
+    int b = 0;
+    for (int f = 0; f < 13; f++) {
+        L->base[f] = b;
+        b += f < 3 ? Q : (f < 9 ? N * D : D * D);
+    }
+    memset(cnt, 0, lines_total(N));
+}
+
+static inline void lines_of(const lines_t* L, int i, int j, int k, int idx[13]) {
+    const int N = L->N, D = L->D, o = N - 1;
+    idx[0] = L->base[0] + j * N + k;
+    idx[1] = L->base[1] + i * N + k;
+    idx[2] = L->base[2] + i * N + j;
+    idx[3] = L->base[3] + k * D + (i - j + o);
+    idx[4] = L->base[4] + k * D + (i + j);
+    idx[5] = L->base[5] + j * D + (i - k + o);
+    idx[6] = L->base[6] + j * D + (i + k);
+    idx[7] = L->base[7] + i * D + (j - k + o);
+    idx[8] = L->base[8] + i * D + (j + k);
+    idx[9] = L->base[9] + (i - j + o) * D + (i - k + o);
+    idx[10] = L->base[10] + (i - j + o) * D + (i + k);
+    idx[11] = L->base[11] + (i + j) * D + (i - k + o);
+    idx[12] = L->base[12] + (i + j) * D + (i + k);
+}
+
+static inline void lines_add(lines_t* L, int i, int j, int k, int d) {
+    int idx[13];
+    lines_of(L, i, j, k, idx);
+    for (int f = 0; f < 13; f++) L->cnt[idx[f]] = (uint8_t)(L->cnt[idx[f]] + d);
+}
+
+static inline int lines_sum(const lines_t* L, int i, int j, int k) {
+    int idx[13], c = 0;
+    lines_of(L, i, j, k, idx);
+    for (int f = 0; f < 13; f++) c += L->cnt[idx[f]];
+    return c;
+}
+
+static int lines_energy(const lines_t* L) {
+    int e = 0;
+    const size_t n = lines_total(L->N);
+    for (size_t t = 0; t < n; t++) e += L->cnt[t] * (L->cnt[t] - 1) / 2;
+    return e;
+}
+
+static int run_board_chain_fast(const job_t* jb, int64_t r) {
+    const mcq_params* p = jb->p;
+    const mcq_outputs* o = jb->out;
+    const int N = p->N, Q = N * N;
+    int* h = (int*)malloc(sizeof(int) * (size_t)Q * 2);
+    uint8_t* cnt = (uint8_t*)malloc(lines_total(N));
+    if (!h || !cnt) {
+        free(h), free(cnt);
+        return MCQ_ENOMEM;
+    }
+    int* best_h = h + Q;
+    rng_t rng;
+    rng_seed(&rng, p->rng, jb->seeds[r]);
+    if (board_init(N, p->init, &rng, h) != 0) {
+        free(h), free(cnt);
+        return MCQ_EINVAL;
+    }
+    lines_t L;
+    lines_setup(&L, N, cnt);
+    for (int c = 0; c < Q; c++) lines_add(&L, c / N, c % N, h[c], 1);
+    int E = lines_energy(&L);
+    memcpy(best_h, h, sizeof(int) * (size_t)Q);
+    int best = E;
+    int64_t best_step = 0, accepted = 0, no_improve = 0, ties = 0, len = 1, executed = 0;
+    int32_t* hist = o->energy_hist ? o->energy_hist + r * p->hist_stride : NULL;
+    uint64_t* bits = o->accept_bits ? o->accept_bits + r * p->bits_stride : NULL;
+    if (hist) hist[0] = E;
+    if (bits)
+        for (int64_t w = 0; w < p->bits_stride; w++) bits[w] = 0;
+    if (o->initial_energy) o->initial_energy[r] = E;
+    for (int64_t step = 0; step < p->n_steps; step++) {
+        double beta = beta_at(p, step);
+        int i = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        int j = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        int old_k = h[i * N + j];
+        int new_k = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        while (new_k == old_k) new_k = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+        /* the moving queen sits on every line through the old cell (-13) and, of the lines through the new cell, only on
+         * the column (i, j), which holds nobody else: both cells count it once there, so that family cancels */
+        int dE = lines_sum(&L, i, j, new_k) - lines_sum(&L, i, j, old_k) + 12;
+        int acc = accept_move(&rng, beta, dE, &ties);
+        executed++;
+        int improved = 0;
+        if (acc) {
+            if (bits) bits[step >> 6] |= 1ull << (step & 63);
+            lines_add(&L, i, j, old_k, -1);
+            lines_add(&L, i, j, new_k, 1);
+            h[i * N + j] = new_k;
+            E += dE;
+            accepted++;
+            if (E < best) {
+                best = E;
+                memcpy(best_h, h, sizeof(int) * (size_t)Q);
+                no_improve = 0;
+                improved = 1;
+            } else {
+                no_improve++;
+            }
+        } else {
+            no_improve++;
+        }
+        if (p->patience >= 0 && no_improve >= p->patience) break;
+        if (hist) hist[len] = E;
+        if (improved) best_step = len;
+        len++;
+    }
+    if (o->hist_len) o->hist_len[r] = len;
+    if (o->steps_executed) o->steps_executed[r] = executed;
+    if (o->best_energy) o->best_energy[r] = best;
+    if (o->final_energy) o->final_energy[r] = E;
+    if (o->steps_to_best) o->steps_to_best[r] = best_step;
+    if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->near_ties) o->near_ties[r] = ties;
+    if (o->best_state)
+        for (int c = 0; c < Q; c++) o->best_state[r * Q + c] = (uint8_t)best_h[c];
+    if (o->final_state)
+        for (int c = 0; c < Q; c++) o->final_state[r * Q + c] = (uint8_t)h[c];
+    free(h), free(cnt);
+    return MCQ_OK;
+}
+
+static int run_full_chain_fast(const job_t* jb, int64_t r) {
+    const mcq_params* p = jb->p;
+    const mcq_outputs* o = jb->out;
+    const int N = p->N, Q = N * N;
+    cell_t* q = (cell_t*)malloc(sizeof(cell_t) * (size_t)Q * 2);
+    uint8_t* occ = (uint8_t*)malloc((size_t)N * N * N);
+    uint8_t* cnt = (uint8_t*)malloc(lines_total(N));
+    if (!q || !occ || !cnt) {
+        free(q), free(occ), free(cnt);
+        return MCQ_ENOMEM;
+    }
+    cell_t* best_q = q + Q;
+    rng_t rng;
+    rng_seed(&rng, p->rng, jb->seeds[r]);
+    if (full_init(N, p->init, &rng, q, occ) != 0) {
+        free(q), free(occ), free(cnt);
+        return MCQ_EINVAL;
+    }
+    lines_t L;
+    lines_setup(&L, N, cnt);
+    for (int c = 0; c < Q; c++) lines_add(&L, q[c].i, q[c].j, q[c].k, 1);
+    int E = lines_energy(&L);
+    memcpy(best_q, q, sizeof(cell_t) * (size_t)Q);
+    int best = E;
+    int64_t best_step = 0, accepted = 0, ties = 0, len = 1;
+    int32_t* hist = o->energy_hist ? o->energy_hist + r * p->hist_stride : NULL;
+    uint64_t* bits = o->accept_bits ? o->accept_bits + r * p->bits_stride : NULL;
+    if (hist) hist[0] = E;
+    if (bits)
+        for (int64_t w = 0; w < p->bits_stride; w++) bits[w] = 0;
+    if (o->initial_energy) o->initial_energy[r] = E;
+    for (int64_t step = 0; step < p->n_steps; step++) {
+        double beta = beta_at(p, step);
+        int qi = (int)mt_bounded(&rng, (uint32_t)(Q - 1));
+        cell_t od = q[qi], nw;
+        for (;;) {
+            nw.i = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+            nw.j = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+            nw.k = (int)mt_bounded(&rng, (uint32_t)(N - 1));
+            if (!occ[(nw.i * N + nw.j) * N + nw.k]) break;
+        }
+        /* old cell: the moving queen is on all 13 of its lines; new cell: on at most one (iff the two cells attack) */
+        int dE = (lines_sum(&L, nw.i, nw.j, nw.k) - full_attacks(od, nw)) - (lines_sum(&L, od.i, od.j, od.k) - 13);
+        int acc = accept_move(&rng, beta, dE, &ties);
+        if (acc) {
+            if (bits) bits[step >> 6] |= 1ull << (step & 63);
+            lines_add(&L, od.i, od.j, od.k, -1);
+            lines_add(&L, nw.i, nw.j, nw.k, 1);
+            occ[(od.i * N + od.j) * N + od.k] = 0;
+            occ[(nw.i * N + nw.j) * N + nw.k] = 1;
+            q[qi] = nw;
+            E += dE;
+            accepted++;
+            if (E < best) {
+                best = E;
+                memcpy(best_q, q, sizeof(cell_t) * (size_t)Q);
+                best_step = len;
+            }
+        }
+        if (hist) hist[len] = E;
+        len++;
+    }
+    if (o->hist_len) o->hist_len[r] = len;
+    if (o->steps_executed) o->steps_executed[r] = p->n_steps;
+    if (o->best_energy) o->best_energy[r] = best;
+    if (o->final_energy) o->final_energy[r] = E;
+    if (o->steps_to_best) o->steps_to_best[r] = best_step;
+    if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->near_ties) o->near_ties[r] = ties;
+    for (int c = 0; c < Q; c++) {
+        if (o->best_state) {
+            uint8_t* d = o->best_state + ((size_t)r * Q + c) * 3;
+            d[0] = (uint8_t)best_q[c].i, d[1] = (uint8_t)best_q[c].j, d[2] = (uint8_t)best_q[c].k;
+        }
+        if (o->final_state) {
+            uint8_t* d = o->final_state + ((size_t)r * Q + c) * 3;
+            d[0] = (uint8_t)q[c].i, d[1] = (uint8_t)q[c].j, d[2] = (uint8_t)q[c].k;
+        }
+    }
+    free(q), free(occ), free(cnt);
+    return MCQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
  * fan-out: one task per chain, chain r seeded with seeds[r] (experiments.py:507-517)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -580,16 +818,22 @@ typedef struct {
     pthread_mutex_t mu;
 } pool_t;
 
+static int run_chain(const job_t* jb, int64_t r) {
+    if (jb->fast) return jb->p->mode == MCQ_MODE_BOARD ? run_board_chain_fast(jb, r) : run_full_chain_fast(jb, r);
+    return jb->p->mode == MCQ_MODE_BOARD ? run_board_chain(jb, r) : run_full_chain(jb, r);
+}
+
 static int run_one(const job_t* jb, int64_t r) {
     if (jb->p->n_sets > 1) { /* batched schedules: chain r follows sets[r / chains_per_set] */
         const mcq_schedule* sc = &jb->p->sets[r / jb->p->chains_per_set];
         mcq_params q = *jb->p;
         job_t one = *jb;
         q.sched = sc->sched, q.beta_const = sc->beta_const, q.beta_start = sc->beta_start, q.beta_end = sc->beta_end;
+        if (q.beta_table) q.beta_table += (r / jb->p->chains_per_set) * q.n_steps; /* set-major table */
         one.p = &q;
-        return q.mode == MCQ_MODE_BOARD ? run_board_chain(&one, r) : run_full_chain(&one, r);
+        return run_chain(&one, r);
     }
-    return jb->p->mode == MCQ_MODE_BOARD ? run_board_chain(jb, r) : run_full_chain(jb, r);
+    return run_chain(jb, r);
 }
 
 static void* worker(void* arg) {
@@ -609,7 +853,17 @@ static void* worker(void* arg) {
     return NULL;
 }
 
+static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads, int fast);
+
 int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads) {
+    return oracle_run_impl(p, seeds, out, n_threads, 0);
+}
+
+int mcq_oracle_run_fast(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads) {
+    return oracle_run_impl(p, seeds, out, n_threads, 1);
+}
+
+static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads, int fast) {
     if (!p || !seeds || !out) return fail(MCQ_EINVAL, "null argument");
     if (p->abi_version != MCQ_ABI_VERSION) return fail(MCQ_EINVAL, "abi_version mismatch");
     if (p->N < MCQ_MIN_N || p->N > MCQ_MAX_N) return fail(MCQ_EINVAL, "N out of range");
@@ -631,7 +885,7 @@ int mcq_oracle_run(const mcq_params* p, const uint32_t* seeds, const mcq_outputs
     if (p->trace == MCQ_TRACE_I32 && (!out->energy_hist || !out->accept_bits))
         return fail(MCQ_EINVAL, "trace requested without buffers");
 
-    job_t jb = {p, seeds, out};
+    job_t jb = {p, seeds, out, fast};
     if (n_threads <= 1) {
         for (int64_t r = 0; r < p->n_chains; r++) {
             int rc = run_one(&jb, r);

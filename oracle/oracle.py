@@ -36,6 +36,8 @@ def lib():
         L = C.CDLL(_SO)
         L.mcq_oracle_run.restype = C.c_int
         L.mcq_oracle_run.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.c_int]
+        L.mcq_oracle_run_fast.restype = C.c_int
+        L.mcq_oracle_run_fast.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Outputs), C.c_int]
         L.mcq_oracle_last_error.restype = C.c_char_p
         L.mcq_oracle_rng_stream.restype = C.c_int
         L.mcq_oracle_rng_stream.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]
@@ -47,8 +49,10 @@ def lib():
     return _lib
 
 
-def run(params, seeds, trace=True, states=True, n_threads=1):
-    """Run every chain on the CPU; returns {field: ndarray} shaped as abi.output_shapes()."""
+def run(params, seeds, trace=True, states=True, n_threads=1, fast=False, host_beta=True):
+    """Run every chain on the CPU; returns {field: ndarray} shaped as abi.output_shapes().  fast=True: the line-counter
+    variant (mcq_oracle_run_fast), same results.  host_beta=False: beta from the oracle's own libm evaluation of the schedule
+    instead of abi.beta_values (NumPy, the reference's arithmetic)."""
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
     assert seeds.shape == (params.n_chains,)
     arrays = {k: np.zeros(shape, dtype=abi.OUTPUT_DTYPES[k])
@@ -58,7 +62,11 @@ def run(params, seeds, trace=True, states=True, n_threads=1):
         setattr(out, k, a.ctypes.data)
     p = abi.copy_params(params)
     p.trace = abi.trace_mode(trace)
-    rc = lib().mcq_oracle_run(C.byref(p), seeds.ctypes.data, C.byref(out), int(n_threads))
+    tab = abi.host_beta_table(p) if (host_beta and not p.beta_table) else None  # the reference's own beta values, like the GPU path gets
+    if tab is not None:
+        p.beta_table = tab.ctypes.data
+    fn = lib().mcq_oracle_run_fast if fast else lib().mcq_oracle_run
+    rc = fn(C.byref(p), seeds.ctypes.data, C.byref(out), int(n_threads))
     if rc != 0:
         msg = lib().mcq_oracle_last_error().decode()
         raise (ValueError if rc == abi.EINVAL else RuntimeError)(msg)

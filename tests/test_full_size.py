@@ -51,24 +51,32 @@ def _full3d_energy(torch, coords, Q):
     return _attacks(torch, d[:, :, 0], d[:, :, 1], d[:, :, 2]).sum(dim=1)
 
 
-def _check_run(mode, N, n_steps, n_chains, sp, n_sample):
+def _check_run(mode, N, n_steps, n_chains, sp, n_sample, init="random", base_seed=42, trace=True, sets=None, chains_per_set=0, seeds=None):
+    """One launch at full size, every chain checked through the properties above; `sets` = schedule sets (one launch, the
+    beta pairs of run_beta_start_end_pairs), trace=False = measure_min_energy_vs_N's shape (no history leaves the kernel)."""
     import torch
 
-    p = abi.make_params(N, n_steps, "random", sp, n_chains, mcmc_type=mode, early_stop_patience=None)
-    seeds = abi.seeds_for(42, n_chains)
-    run = mcq_amd._lib.DeviceRun(p, seeds, trace=True, states=True)
+    if sets is not None:
+        p = abi.make_params_sets(N, n_steps, init, sets, chains_per_set, mcmc_type=mode, early_stop_patience=None, trace=trace)
+        n_chains = len(sets) * chains_per_set
+    else:
+        p = abi.make_params(N, n_steps, init, sp, n_chains, mcmc_type=mode, early_stop_patience=None, trace=trace)
+    if seeds is None:
+        seeds = abi.seeds_for(base_seed, n_chains)
+    run = mcq_amd._lib.DeviceRun(p, seeds, trace=trace, states=True)
     run.launch()
     torch.cuda.synchronize()
     t = run.t
     dev = t["best_energy"].device
     Q = N * N
     tabs = _pair_tables(torch, N, dev) if mode == "board" else None
-    bits8 = t["accept_bits"].view(torch.uint8)  # little-endian: step s is bit s % 8 of byte s // 8
-    shifts = torch.arange(8, device=dev, dtype=torch.uint8)
     assert bool((t["hist_len"] == n_steps + 1).all()) and bool((t["steps_executed"] == n_steps).all())
-    for lo in range(0, n_chains, CHUNK):
-        sl = slice(lo, min(n_chains, lo + CHUNK))
-        hist = t["energy_hist"][sl, : n_steps + 1]
+    if trace:
+        bits8 = t["accept_bits"].view(torch.uint8)  # little-endian: step s is bit s % 8 of byte s // 8
+        shifts = torch.arange(8, device=dev, dtype=torch.uint8)
+    chunk = CHUNK if N <= 16 else CHUNK // 4
+    for lo in range(0, n_chains, chunk):
+        sl = slice(lo, min(n_chains, lo + chunk))
         # states against energies
         if mode == "board":
             e_final = _board_energy(torch, t["final_state"][sl], N, tabs)
@@ -78,6 +86,10 @@ def _check_run(mode, N, n_steps, n_chains, sp, n_sample):
             e_best = _full3d_energy(torch, t["best_state"][sl], Q)
         assert torch.equal(e_final, t["final_energy"][sl].to(torch.int64)), f"final state energy, chains {lo}.."
         assert torch.equal(e_best, t["best_energy"][sl].to(torch.int64)), f"best state energy, chains {lo}.."
+        assert bool((t["best_energy"][sl] <= t["initial_energy"][sl]).all()) and bool((t["best_energy"][sl] <= t["final_energy"][sl]).all())
+        if not trace:
+            continue
+        hist = t["energy_hist"][sl, : n_steps + 1]
         # the trace against the scalars
         assert torch.equal(hist[:, 0], t["initial_energy"][sl])
         assert torch.equal(hist[:, n_steps], t["final_energy"][sl])
@@ -91,16 +103,23 @@ def _check_run(mode, N, n_steps, n_chains, sp, n_sample):
         assert not bool((changed & ~acc).any()), "energy changed on a rejected step"
         assert torch.equal(acc.sum(dim=1), t["n_accepted"][sl])
         del acc, changed, first, best
-    # both ends of the batch against the oracle
-    idx = np.r_[0:n_sample, n_chains - n_sample:n_chains]
-    ps = abi.make_params(N, n_steps, "random", sp, len(idx), mcmc_type=mode, early_stop_patience=None)
-    want = oracle.run(ps, seeds[idx], n_threads=8)
+    # both ends of the batch (of every schedule set) against the oracle
+    if sets is not None:
+        idx = np.concatenate([np.r_[s * chains_per_set:s * chains_per_set + n_sample, (s + 1) * chains_per_set - n_sample:(s + 1) * chains_per_set]
+                              for s in range(len(sets))])
+        ps = abi.make_params_sets(N, n_steps, init, sets, 2 * n_sample, mcmc_type=mode, early_stop_patience=None, trace=trace)
+    else:
+        idx = np.r_[0:n_sample, n_chains - n_sample:n_chains]
+        ps = abi.make_params(N, n_steps, init, sp, len(idx), mcmc_type=mode, early_stop_patience=None, trace=trace)
+    want = oracle.run(ps, seeds[idx], trace=trace, n_threads=16, fast=N > 16)  # (the line-counter oracle equals the naive one: test_oracle_fast.py)
     ti = torch.from_numpy(idx).to(dev)
     for k in ("initial_energy", "best_energy", "final_energy", "steps_to_best", "n_accepted", "near_ties", "best_state", "final_state"):
         np.testing.assert_array_equal(t[k][ti].cpu().numpy(), want[k], err_msg=k)
-    np.testing.assert_array_equal(t["energy_hist"][ti].cpu().numpy()[:, : n_steps + 1], want["energy_hist"][:, : n_steps + 1])
-    np.testing.assert_array_equal(t["accept_bits"][ti].cpu().numpy().view(np.uint64), want["accept_bits"])
+    if trace:
+        np.testing.assert_array_equal(t["energy_hist"][ti].cpu().numpy()[:, : n_steps + 1], want["energy_hist"][:, : n_steps + 1])
+        np.testing.assert_array_equal(t["accept_bits"][ti].cpu().numpy().view(np.uint64), want["accept_bits"])
     assert int(t["near_ties"].sum().item()) == 0
+    return int(t["best_energy"].min().item())
 
 
 @pytest.mark.gpu
@@ -113,5 +132,54 @@ def test_headline_size_board():
 @pytest.mark.gpu
 @pytest.mark.timeout(1500)
 def test_config3_size_full3d():
-    """BASELINE.json configs[2] at a fifth of its length: N=12 full_3d, exponential 1 -> 3, 65 536 chains x 20 000 steps"""
-    _check_run("full_3d", 12, 20000, 65536, {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, n_sample=8)
+    """BASELINE.json configs[2] at its full size: N=12 full_3d, exponential 1 -> 3, 65 536 chains x 100 000 steps, full trace"""
+    _check_run("full_3d", 12, 100000, 65536, {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}, n_sample=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_config5_size_pairs():
+    """BASELINE.json configs[4] at its full size, one GPU: N=24 board, sinusoidal, 16 (beta_start, beta_end) pairs x 8 192 chains
+    x 100 000 steps as ONE launch with 16 schedule sets, pair seeds base_seed + idx * 1000 (experiments.py:791), full trace
+    (52 GB, resident in HBM) so that every chain's history is checked against its scalars, accept bits and states."""
+    pairs = [(s, e) for s in (0.1, 0.5, 1.0, 2.0) for e in (2.0, 3.0, 5.0, 8.0)]
+    sets = [{"type": "sinusoidal_annealing", "beta_start": s, "beta_end": e} for s, e in pairs]
+    seeds = np.concatenate([abi.seeds_for(42 + 1000 * i, 8192) for i in range(16)])
+    _check_run("board", 24, 100000, 0, None, n_sample=8, sets=sets, chains_per_set=8192, seeds=seeds)  # 2 x 8 chains per pair: 16-chain sets for the oracle
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_config4_size_cells():
+    """BASELINE.json configs[3] at its full grid, one GPU: Ns = 3..20 x {random, latin, klarner}, linear 1 -> 3, board,
+    8 192 chains per cell x 100 000 steps, seeds base_seed + 10 * idx + sum(ord) % 1000 (experiments.py:1060-1067), no trace
+    (that driver discards histories): every chain's best / final state recounted pair by pair, both ends of every cell
+    against the oracle; known answers: klarner boards with gcd(N, 210) == 1 start at energy 0 (mcmc_board.py:21)."""
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    for init in ("random", "latin", "klarner"):
+        off = sum(ord(c) for c in init) % 1000
+        for idx, N in enumerate(range(3, 21)):
+            mn = _check_run("board", N, 100000, 8192, sp, n_sample=2, init=init, base_seed=42 + 10 * idx + off, trace=False)
+            if init == "klarner" and N in (11, 13, 17, 19):
+                assert mn == 0
+
+
+@pytest.mark.gpu
+def test_competition_writer_on_the_gpu(tmp_path):
+    """competition.py:143-187 at its own size through the real path: N=15, 10 runs, 10^5 steps, linear 1 -> 3, seeds 42..51; the
+    written board is recounted pair by pair and compared with the oracle's best board."""
+    best, heights, path = mcq_amd.drivers.run_competition(out_dir=str(tmp_path), timestamp="t")
+    lines = open(path).read().split()
+    assert path.endswith("best_heights_15_t.txt") and len(lines) == 225 and lines[0].startswith("0,0,") and lines[-1].startswith("14,14,")
+    cells = np.array([[int(v) for v in ln.split(",")] for ln in lines])
+    assert (cells[:, 0] == np.repeat(np.arange(15), 15)).all() and (cells[:, 1] == np.tile(np.arange(15), 15)).all()
+    a, b = np.triu_indices(225, k=1)
+    d = np.abs(cells[a] - cells[b])
+    m = d.max(axis=1)
+    assert int((((d == 0) | (d == m[:, None])).all(axis=1)).sum()) == best
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    p = abi.make_params(15, 100000, "random", sp, 10, mcmc_type="board", trace=False)
+    want = oracle.run(p, abi.seeds_for(42, 10), trace=False, n_threads=10, fast=True)
+    r = int(np.argmin(want["best_energy"]))
+    assert best == int(want["best_energy"][r])
+    np.testing.assert_array_equal(heights.reshape(-1), want["best_state"][r])

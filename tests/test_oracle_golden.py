@@ -103,6 +103,24 @@ def test_beta_tables(golden):
             np.testing.assert_array_equal(got, want, err_msg=str(c))
 
 
+def test_host_beta_values_are_the_references(golden):
+    """abi.beta_values (what the sweep is given as mcq_params.beta_table) against the reference's closures, bit for bit for all
+    five schedules -- it calls the same NumPy functions in the same order (experiments.py:13-77)."""
+    z = golden.npz("beta")
+    for c in golden.manifest["beta"]:
+        got = abi.beta_values(c["schedule"], c["n_steps"])[z[c["key"] + "_steps"]]
+        np.testing.assert_array_equal(got, z[c["key"] + "_beta"], err_msg=str(c))
+    sets = [{"type": "sinusoidal_annealing", "beta_start": 0.1, "beta_end": 2.0}, {"type": "exponential_annealing", "beta_start": 1.0, "beta_end": 3.0}]
+    p = abi.make_params_sets(6, 50, "random", sets, 16, mcmc_type="board")
+    tab = abi.host_beta_table(p)
+    assert tab.shape == (2, 50)
+    np.testing.assert_array_equal(tab[1], abi.beta_values(sets[1], 50))
+    # the oracle follows the table it is given; its own libm evaluation differs from it by at most an ulp
+    a = oracle.run(p, abi.seeds_for(3, 32))
+    b = oracle.run(p, abi.seeds_for(3, 32), host_beta=False)
+    util.assert_results_equal(a, b, "oracle with the reference's beta values vs its own evaluation")
+
+
 def test_threads_do_not_change_results():
     sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
     p = abi.make_params(7, 500, "random", sp, 13, mcmc_type="full_3d")
