@@ -139,7 +139,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         sp = {"type": "constant", "beta_const": 5.0}
     else:
         sp = {"type": args.schedule, "beta_start": 1.0, "beta_end": 3.0}
-    trace = not args.no_trace
+    trace = {"i32": True, "none": False, "reduced": "reduced"}["none" if args.no_trace else args.trace]
     base_seed = 42
     p = abi.make_params(args.N, args.n_steps, "random", sp, args.chains, mcmc_type=args.mcmc_type,
                         early_stop_patience=None, trace=trace, lanes_per_chain=args.lanes, rng=args.rng)
@@ -165,10 +165,10 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
     value = sm["proposed"] * args.steps / elapsed
     sweep_avg_ms = sum(sweep_ms) / len(sweep_ms)
     local_moves = int(run.t["steps_executed"].sum().item())
-    algo_bytes = ALGO_BYTES_PER_MOVE * local_moves if trace else 0.0
+    algo_bytes = ALGO_BYTES_PER_MOVE * local_moves if trace is True else 0.0
     achieved = algo_bytes / (sweep_avg_ms * 1e-3) / 1e9
 
-    key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}" + ("" if args.rng == "mt19937" else f"_{args.rng}") + ("" if trace else "_notrace")
+    key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}" + ("" if args.rng == "mt19937" else f"_{args.rng}") + ("" if trace is True else "_notrace" if trace is False else "_reduced")
     pmc, why = measured_traffic(key)
     line = {
         "metric": METRIC,
@@ -187,7 +187,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         "config": {
             "workload": f"single_N N={args.N} mcmc_type={args.mcmc_type} init=random {args.schedule} "
                         f"{sp.get('beta_start', sp.get('beta_const'))}->{sp.get('beta_end', '')} "
-                        f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace else 'none'}"
+                        f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace is True else 'none' if trace is False else 'reduced'}"
                         + ("" if args.rng == "mt19937" else f" rng={args.rng} (NOT the reference's stream)"),
             "chains_total": total_chains,
             "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes_n(run.p.mode, run.p.N)),
@@ -224,15 +224,16 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
 
         threads = args.cpu_threads or usable_cpus()
         n_cpu = min(args.cpu_chains, args.chains)
-        pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=trace, rng=args.rng)
+        ctrace = trace is True
+        pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=ctrace, rng=args.rng)
         t1 = time.perf_counter()
-        cres = oracle.run(pc, seeds[:n_cpu], trace=trace, states=True, n_threads=threads)
+        cres = oracle.run(pc, seeds[:n_cpu], trace=ctrace, states=True, n_threads=threads)
         dt = time.perf_counter() - t1
         # the whole sample against the GPU: every integer output, trace and states included
         same = True
         for k in ("hist_len", "initial_energy", "best_energy", "final_energy", "steps_to_best", "n_accepted", "best_state", "final_state"):
             same = same and bool(np.array_equal(run.t[k][:n_cpu].cpu().numpy(), cres[k]))
-        if trace:
+        if ctrace:
             same = same and bool(np.array_equal(run.t["energy_hist"][:n_cpu, : args.n_steps + 1].cpu().numpy(), cres["energy_hist"][:, : args.n_steps + 1]))
             same = same and bool(np.array_equal(run.t["accept_bits"][:n_cpu].cpu().numpy().view(np.uint64), cres["accept_bits"]))
         del cres
@@ -338,7 +339,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (4, 8 or 16; 0 = library default)")
     ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
                     help="mt19937 = NumPy's stream (reference-identical, the bench default); philox = counter-based fast mode (evidence only)")
-    ap.add_argument("--no-trace", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="same as --trace none")
+    ap.add_argument("--trace", default="i32", choices=["i32", "none", "reduced"],
+                    help="c2 / c3: full int32 energy trace (the headline), no trace, or per-step sums accumulated on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = every CPU this process may use)")

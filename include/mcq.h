@@ -75,10 +75,12 @@ extern "C" {
 #define MCQ_MIN_N 2
 #define MCQ_MAX_N 32
 
-/* One beta schedule of a batched run (run_beta_start_end_pairs loops over such pairs: experiments.py:741-846). */
+/* One set of a batched run: its beta schedule (run_beta_start_end_pairs loops over such pairs: experiments.py:741-846) and,
+ * optionally, its own init mode. */
 typedef struct mcq_schedule {
     int32_t sched;     /* MCQ_SCHED_* */
-    int32_t reserved;  /* 0 */
+    int32_t init_plus1; /* 0: the set starts from mcq_params.init; otherwise MCQ_INIT_* + 1 -- the (init_mode, N) cells of
+                           measure_min_energy_vs_N that share N (experiments.py:1050-1067) then run as one launch */
     double beta_const;
     double beta_start;
     double beta_end;

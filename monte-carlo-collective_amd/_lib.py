@@ -13,6 +13,13 @@ from . import abi, build as _build
 
 _lib = None
 
+# The drivers run many small launches concurrently (one HIP stream per (init_mode, N) cell or beta pair).  The HIP runtime maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and launches that share a queue run one after the other: with the
+# default, the 18 launches of measure_min_energy_vs_N at 3 x 1 024 chains each run at a third of the rate they reach with 16
+# queues (profiles/r02_small_launches.txt).  The variable is read when the HIP runtime initialises, so it is set here, at
+# import, unless the user has chosen a value; it does not affect single-stream runs.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 
 class McqError(RuntimeError):
     pass

@@ -35,7 +35,7 @@ class Schedule(C.Structure):
     """include/mcq.h: mcq_schedule -- one beta schedule of a batched run"""
     _fields_ = [
         ("sched", C.c_int32),
-        ("reserved", C.c_int32),
+        ("init_plus1", C.c_int32),
         ("beta_const", C.c_double),
         ("beta_start", C.c_double),
         ("beta_end", C.c_double),
@@ -184,10 +184,11 @@ def _check_schedule(schedule_params):
 
 
 def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_type="full_3d", early_stop_patience=None,
-                     trace=True, flags=0, lanes_per_chain=0, device=-1, rng="mt19937"):
+                     trace=True, flags=0, lanes_per_chain=0, device=-1, rng="mt19937", init_modes=None):
     """Parameters of ONE launch that runs `chains_per_set` chains under each schedule of `schedule_sets` (a list of
     betta_scheduling dicts): chains [t * chains_per_set, (t + 1) * chains_per_set) follow schedule t.  What
-    run_beta_start_end_pairs does pair by pair (experiments.py:741-846), batched."""
+    run_beta_start_end_pairs does pair by pair (experiments.py:741-846), batched.  `init_modes` (optional, one per set) gives
+    every set its own initial state: the (init_mode, N) cells of measure_min_energy_vs_N that share N."""
     sets = [_check_schedule(sp) for sp in schedule_sets]
     if not sets:
         raise ValueError("at least one schedule")
@@ -197,8 +198,14 @@ def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_
                     early_stop_patience=early_stop_patience, trace=trace, flags=flags, lanes_per_chain=lanes_per_chain, device=device,
                     rng=rng)
     arr = (Schedule * len(sets))()
-    for a, (st, bc, bs, be) in zip(arr, sets):
-        a.sched, a.reserved, a.beta_const, a.beta_start, a.beta_end = SCHED[st], 0, bc, bs, be
+    if init_modes is not None:
+        if len(init_modes) != len(sets):
+            raise ValueError("init_modes needs one entry per schedule set")
+        for im in init_modes:
+            if im not in INIT:
+                raise ValueError(f"Unknown init_mode: {im}")
+    for t, (a, (st, bc, bs, be)) in enumerate(zip(arr, sets)):
+        a.sched, a.init_plus1, a.beta_const, a.beta_start, a.beta_end = SCHED[st], 0 if init_modes is None else INIT[init_modes[t]] + 1, bc, bs, be
     p.n_sets, p.chains_per_set = len(sets), chains_per_set
     p.sets = C.cast(arr, C.POINTER(Schedule))
     p._sets_keepalive = arr  # the struct only holds a pointer

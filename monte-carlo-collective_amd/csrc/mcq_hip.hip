@@ -101,7 +101,10 @@ constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 constexpr int RING = 64;          // ready (tempered) words per chain
 constexpr int RING_MIRROR = 32;   // slots 0..31 are repeated behind the ring: a proposal reads up to 31 slots past pos without wrapping
-constexpr int RED_STRIPES = 8;    // trace == REDUCED: independent accumulator copies, so one address sees few atomics
+#ifndef MCQ_RED_STRIPES
+#define MCQ_RED_STRIPES 8
+#endif
+constexpr int RED_STRIPES = MCQ_RED_STRIPES;  // trace == REDUCED: independent accumulator copies, so one address sees few atomics
 constexpr int REC_MIRROR = 624;   // record word: copy of MT word 0, so that words i+1 and i+397.. of a block never wrap inside a lane's run
 constexpr int REC_POS = 625;      // record word: MT index of the next word to consume
 constexpr int REC_GEN_END = 626;  // record word: words [0, gen_end) belong to the current generation
@@ -807,7 +810,11 @@ __device__ __forceinline__ void reduce_block(const uint32_t* wave_stage, int cha
         sq += ((unsigned long long)(uint32_t)__shfl_xor((int)(sq >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sq, off, 64);
     }
     const long long idx = (long long)e0 + ent;
+#ifdef MCQ_EXP_NO_ATOMICS
+    if (lane < 16 && idx < n_entries && (ac | cn) == 0xffffffffu) {
+#else
     if (lane < 16 && idx < n_entries && (ac | cn) != 0) {
+#endif
         atomicAdd(red + idx, (unsigned long long)se);
         atomicAdd(red + red_len + idx, sq);
         atomicAdd(red + 2 * red_len + idx, (unsigned long long)ac | ((unsigned long long)cn << 32));
@@ -977,11 +984,17 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
     int last_entry = n_steps;  // wave-uniform: the last history entry any chain of the wavefront can have reached
-    for (int vstep = 0; vstep < n_steps; vstep++) {
+    // Every live lane is at the same step, but where lanes can sit the loop body out (early stopping, the idle groups a
+    // reduced-trace wavefront keeps for its reductions) the compiler no longer sees that and would carry the counter -- and with
+    // it the beta table load and every "every 16 / 32 / 64 steps" test -- in vector registers.  The counter therefore goes through
+    // readfirstlane on its way round the loop: it stays a scalar.
+    constexpr bool SCALAR_STEP = PATIENCE || REDUCED;
+    for (int vstep = 0; vstep < n_steps;) {
         STAMP(0);  // loop overhead + previous step's tail
-        // every live lane is at the same step; with early stopping the loop itself may become divergent
-        const int step = PATIENCE ? __builtin_amdgcn_readfirstlane(vstep) : vstep;
+        const int step = SCALAR_STEP ? __builtin_amdgcn_readfirstlane(vstep) : vstep;
+        vstep = step + 1;
         const float c32 = c32_tab[step];  // exp(-beta dE) = exp2(dE * c32)
+        bool some_stopped = false;        // wave-uniform: a chain of this wavefront stopped early in this step
 
         if (active) {
             // ---- proposal draws -----------------------------------------------------------------
@@ -1055,7 +1068,11 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
 
             // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
             // the old height (with four, the 16 extra live registers would spill)
+#ifdef MCQ_EXP_EARLY_RED
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3;
+#else
             constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3 && !REDUCED;
+#endif
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);
@@ -1247,7 +1264,13 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         const uint32_t wr = crow[m], wc = cw[cj], wd = cw[m - ci + cj], wa = cw[ci + cj - m];
                         const uint32_t Mrc = pk_star2(BB, abs_diff(m, cj) | (abs_diff(m, ci) << 16));
                         const uint32_t Mcc = __builtin_amdgcn_perm(Mrc, Mrc, 0x03020302u);  // the column-distance mask in both halves
-                        const uint32_t vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1), va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1);
+                        uint32_t vd, va;  // all ones iff the diagonal / anti-diagonal probe (m, m - ci + cj) / (m, ci + cj - m) is on the board
+                        if constexpr (NT >= 4) {  // four passes: the lane-constant tables would not fit the register file (one spill); compare instead
+                            vd = krc[t] != 0u && (unsigned)(m - ci + cj) < (unsigned)N ? 0xffffffffu : 0u;
+                            va = krc[t] != 0u && (unsigned)(ci + cj - m) < (unsigned)N ? 0xffffffffu : 0u;
+                        } else {
+                            vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1), va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1);
+                        }
                         cnt += __popc((wr | (wc << 16)) & Mrc & krc[t]);
                         cnt += __popc(((wd & vd) | ((wa & va) << 16)) & Mcc);
                     }
@@ -1334,21 +1357,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 }
             }
 
-            if (PATIENCE && no_imp >= patience) {
-                // break BEFORE the append (experiments.py:349-353): entries 0..step are valid
-                active = false;
-                cold[C_HIST_LEN] = e;
-                if constexpr (REDUCED) {  // this step counts as executed / accepted but appends no entry; the rest of the block is stale
-#pragma unroll
-                    for (int w = 0; w < WPL; w++)
-                        if (gl * WPL + w >= (e & 15)) stage[gl * WPL + w] = gl * WPL + w == (e & 15) && acc ? 0x80000000u : 0u;
-                }
-                if (trace)
-                    for (int w = 0; w < WPL; w++)
-                        if (gl * WPL + w <= (step & 15)) hist_at(step & ~15)[w] = (int)stage[gl * WPL + w];
-                cold[C_N_ACC] += __popc(accw);
-                if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
-            } else {
+            // the common tail of a step: append the entry, flush full blocks, pace
+            auto append_entry = [&]() {
                 stage[e & 15] = (uint32_t)E | (reduced ? (acc ? 0xC0000000u : 0x40000000u) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
                 if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
 #ifdef MCQ_EXP_NT_TRACE
@@ -1375,6 +1385,35 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         set_priority(min(3, (int)__popcll(__ballot(other > mine))));
                     }
                 }
+            };
+            if constexpr (PATIENCE) {
+                // Early stop (experiments.py:349-353).  A chain stops in few steps of a run, so the test is one wave-wide ballot and
+                // the step's tail runs undivided unless some chain of the wavefront stops right now.
+                const bool stop = no_imp >= patience;
+                if (__builtin_expect(wave_any(stop), 0)) {
+                    some_stopped = true;
+                    if (stop) {
+                        // break BEFORE the append: entries 0..step are valid
+                        active = false;
+                        cold[C_HIST_LEN] = e;
+                        if constexpr (REDUCED) {  // this step counts as executed / accepted but appends no entry; the rest of the block is stale
+#pragma unroll
+                            for (int w = 0; w < WPL; w++)
+                                if (gl * WPL + w >= (e & 15)) stage[gl * WPL + w] = gl * WPL + w == (e & 15) && acc ? 0x80000000u : 0u;
+                        }
+                        if (trace)
+                            for (int w = 0; w < WPL; w++)
+                                if (gl * WPL + w <= (step & 15)) hist_at(step & ~15)[w] = (int)stage[gl * WPL + w];
+                        cold[C_N_ACC] += __popc(accw);
+                        if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
+                    } else {
+                        append_entry();
+                    }
+                } else {
+                    append_entry();
+                }
+            } else {
+                append_entry();
             }
         }
         STAMP(5);  // apply + history
@@ -1385,7 +1424,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 for (int w = 0; w < WPL; w++) stage[gl * WPL + w] = 0u;
             }
         }
-        if (PATIENCE && !wave_any(active)) {
+        if (PATIENCE && some_stopped && !wave_any(active)) {  // (only a step in which a chain stopped can have stopped the last one)
             last_entry = step + 1;
             break;
         }
@@ -1543,8 +1582,10 @@ int validate(const mcq_params* p) {
         if (!p->sets) return fail(MCQ_EINVAL, "n_sets > 1 without sets");
         if (p->chains_per_set <= 0 || p->chains_per_set % 16 != 0) return fail(MCQ_EINVAL, "chains_per_set must be a positive multiple of 16");
         if (p->n_chains != p->n_sets * p->chains_per_set) return fail(MCQ_EINVAL, "n_chains must equal n_sets * chains_per_set");
-        for (int64_t t = 0; t < p->n_sets; t++)
+        for (int64_t t = 0; t < p->n_sets; t++) {
             if (p->sets[t].sched < MCQ_SCHED_CONSTANT || p->sets[t].sched > MCQ_SCHED_SINUSOIDAL) return fail(MCQ_EINVAL, "unknown schedule type in sets");
+            if (p->sets[t].init_plus1 < 0 || p->sets[t].init_plus1 > MCQ_INIT_KLARNER + 1) return fail(MCQ_EINVAL, "Unknown init_mode in sets");
+        }
     }
     return MCQ_OK;
 }
@@ -1771,7 +1812,9 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     {  // behind the state: the permutation array of np.random.choice (full_3d random init), then the E0 line counters
         const size_t D = 2 * (size_t)p->N - 1, lines = ((3 * (size_t)a.Q + 6 * p->N * D + 4 * D * D + 3) / 4) * 4;
-        const size_t perm = p->mode == MCQ_MODE_FULL3D && p->init == MCQ_INIT_RANDOM ? (size_t)p->N * p->N * p->N * 2 : 0;
+        bool any_random = p->init == MCQ_INIT_RANDOM;
+        for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) any_random |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
+        const size_t perm = p->mode == MCQ_MODE_FULL3D && any_random ? (size_t)p->N * p->N * p->N * 2 : 0;
         init_lds += perm > lines ? perm : lines;
     }
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
@@ -1788,7 +1831,29 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
                 hipLaunchKernelGGL(mcq_beta_kernel, dim3((unsigned)((p->n_steps + 255) / 256)), dim3(256), 0, s, b);
         }
     }
-    hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
+    {  // sets may start from different init modes (one launch of the init kernel per distinct run of sets)
+        bool mixed = false;
+        for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) mixed |= p->sets[t].init_plus1 != 0;
+        if (!mixed) {
+            hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
+        } else {
+            for (size_t t = 0; t < n_sets_of(p); t++) {
+                KArgs b = a;
+                b.init = p->sets[t].init_plus1 ? p->sets[t].init_plus1 - 1 : p->init;
+                b.klarner_M = 0;
+                if (b.init == MCQ_INIT_KLARNER && gcd_int(p->N, 210) != 1)
+                    for (int m = p->N - 1; m > 0; m--)
+                        if (gcd_int(m, 210) == 1) {
+                            b.klarner_M = m;
+                            break;
+                        }
+                b.seeds = a.seeds + t * (size_t)p->chains_per_set;
+                b.ws = a.ws + t * (size_t)p->chains_per_set * a.rec_words;
+                b.n_chains = p->chains_per_set;
+                hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->chains_per_set), dim3(64), init_lds, s, b);
+            }
+        }
+    }
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
 

@@ -7,8 +7,9 @@ run_beta_start_end_pairs (experiments.py:777-806), one per (init_mode, N) cell i
 
 * every rank takes the contiguous block [lo, hi) of each job's chains (distributed.shard_bounds), seeds base_seed + global
   index, so results do not depend on the number of GPUs;
-* jobs that differ only in schedule and seeds become ONE launch with schedule sets (mcq_params.sets); the others get a launch
-  and a HIP stream each, all enqueued back to back;
+* jobs that differ only in schedule, init mode and seeds become ONE launch with one set per job (mcq_params.sets): the beta
+  pairs of a pair experiment, the init modes of one N in measure_min_energy_vs_N; the others get a launch and a HIP stream each,
+  all enqueued back to back;
 * nothing but per-chain scalars and, on request, per-step integer sums ever exists: `want="stats"` runs with
   trace = REDUCED, so a job of 8 192 chains x 10^5 steps never materialises its 3.3 GB trace, on the device or on the host;
 * the node-level result is ONE packed SUM all-reduce (distributed.py) -- after it every rank holds the per-job minima,
@@ -79,7 +80,7 @@ class JobSet:
         groups = {}
         for i, j in enumerate(self.jobs):
             n = len(self.shards[i][0])
-            key = (j["N"], j["n_steps"], j["init_mode"], j["mcmc_type"], j["early_stop_patience"], n)
+            key = (j["N"], j["n_steps"], j["mcmc_type"], j["early_stop_patience"], n)  # schedule, init mode and seeds may differ inside a launch
             batchable = n > 0 and n % 16 == 0 and j["schedule_params"] is not None
             groups.setdefault(key if batchable else ("single", i), []).append(i)
         for key, ids in groups.items():
@@ -90,7 +91,7 @@ class JobSet:
             if len(ids) > 1:
                 p = abi.make_params_sets(j0["N"], j0["n_steps"], j0["init_mode"], [self.jobs[i]["schedule_params"] for i in ids], n,
                                          mcmc_type=j0["mcmc_type"], early_stop_patience=j0["early_stop_patience"], trace=self.trace,
-                                         lanes_per_chain=lanes_per_chain, rng=rng)
+                                         lanes_per_chain=lanes_per_chain, rng=rng, init_modes=[self.jobs[i]["init_mode"] for i in ids])
                 seeds = np.concatenate([self.shards[i][0] for i in ids])
             else:
                 p = abi.make_params(j0["N"], j0["n_steps"], j0["init_mode"], j0["schedule_params"], n, mcmc_type=j0["mcmc_type"],
@@ -169,15 +170,17 @@ class JobSet:
     def reduce(self):
         """Pack this rank's results, all-reduce once, and return one dict per job (identical on every rank):
         summary, best_energy[n_runs], steps_to_best[n_runs], and with want="stats" the five per-step arrays."""
-        torch_views = self._local_views() if self.runner is None else self._injected_views()
-        torch = self.torch
         if self.runner is None:
+            torch = self.torch
             cur = torch.cuda.current_stream()
-            for la in self.launches:
+            for la in self.launches:  # everything below runs on the current stream, behind every launch
                 cur.wait_stream(la.stream)
+            torch_views = self._local_views()
             buf = self.buf
             buf.zero_()
         else:
+            torch_views = self._injected_views()
+            torch = self.torch
             dev = "cpu"
             if self.dist is not None and self.dist.is_initialized() and self.dist.get_backend() == "nccl":
                 dev = torch.device("cuda", torch.cuda.current_device())

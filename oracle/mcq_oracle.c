@@ -829,6 +829,7 @@ static int run_one(const job_t* jb, int64_t r) {
         mcq_params q = *jb->p;
         job_t one = *jb;
         q.sched = sc->sched, q.beta_const = sc->beta_const, q.beta_start = sc->beta_start, q.beta_end = sc->beta_end;
+        if (sc->init_plus1) q.init = sc->init_plus1 - 1; /* a set may have its own init mode */
         if (q.beta_table) q.beta_table += (r / jb->p->chains_per_set) * q.n_steps; /* set-major table */
         one.p = &q;
         return run_chain(&one, r);

@@ -319,7 +319,7 @@ def test_buffer_contract_is_checked():
     bad.hist_stride = 101
     assert L.mcq_run_device(C.byref(bad), run.seeds.data_ptr(), C.byref(run.out), run.ws.data_ptr(), run.ws_bytes, st) == abi.EINVAL
     assert b"multiple of 16" in L.mcq_last_error()
-    assert L.mcq_run_device(C.byref(run.p), run.seeds.data_ptr(), C.byref(run.out), run.ws.data_ptr() + 4, run.ws_bytes - 4, st) == abi.EINVAL
+    assert L.mcq_run_device(C.byref(run.p), run.seeds.data_ptr(), C.byref(run.out), run.ws.data_ptr() + 4, run.ws_bytes, st) == abi.EINVAL  # (rejected before anything is touched)
     out = abi.Outputs.from_buffer_copy(run.out)
     out.energy_hist = run.t["energy_hist"].data_ptr() + 4
     assert L.mcq_run_device(C.byref(run.p), run.seeds.data_ptr(), C.byref(out), run.ws.data_ptr(), run.ws_bytes, st) == abi.EINVAL

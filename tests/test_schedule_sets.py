@@ -86,3 +86,31 @@ def test_hip_rejects_bad_sets():
     p.n_chains = 16 * len(SETS) - 16
     with pytest.raises(ValueError):
         mcq_amd._lib.run_host(p, abi.seeds_for(1, p.n_chains))
+
+
+def test_sets_with_their_own_init_mode_cpu():
+    """mcq_schedule.init_plus1: a set may start from its own init mode (the cells of measure_min_energy_vs_N that share N,
+    experiments.py:1050-1067).  Oracle: equals the per-init launches chain for chain."""
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    inits = ["random", "latin", "klarner"]
+    for mode in ("board", "full_3d"):
+        p = abi.make_params_sets(8, 300, "random", [sp] * 3, 16, mcmc_type=mode, init_modes=inits)
+        seeds = np.concatenate([abi.seeds_for(42 + 100 * t, 16) for t in range(3)])
+        got = oracle.run(p, seeds)
+        for t, im in enumerate(inits):
+            one = oracle.run(abi.make_params(8, 300, im, sp, 16, mcmc_type=mode), seeds[16 * t:16 * t + 16])
+            for k in ("initial_energy", "best_energy", "final_energy", "steps_to_best", "n_accepted", "final_state"):
+                np.testing.assert_array_equal(got[k][16 * t:16 * t + 16], one[k], err_msg=f"{mode} {im} {k}")
+    with pytest.raises(ValueError):
+        abi.make_params_sets(8, 10, "random", [sp] * 2, 16, init_modes=["random", "nope"])
+
+
+@pytest.mark.gpu
+def test_sets_with_their_own_init_mode_gpu():
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    inits = ["klarner", "random", "latin", "random"]
+    for mode, N in (("board", 8), ("board", 13), ("full_3d", 6), ("full_3d", 12)):
+        p = abi.make_params_sets(N, 400, "latin", [sp] * 4, 32, mcmc_type=mode, init_modes=inits)
+        seeds = np.concatenate([abi.seeds_for(7 + 100 * t, 32) for t in range(4)])
+        got, _ = mcq_amd._lib.run_host(p, seeds)
+        util.assert_results_equal(got, oracle.run(p, seeds, n_threads=8), f"sets with init modes {mode} N={N}")
