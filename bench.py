@@ -142,7 +142,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
     trace = {"i32": True, "none": False, "reduced": "reduced"}["none" if args.no_trace else args.trace]
     base_seed = 42
     p = abi.make_params(args.N, args.n_steps, "random", sp, args.chains, mcmc_type=args.mcmc_type,
-                        early_stop_patience=None, trace=trace, lanes_per_chain=args.lanes, rng=args.rng)
+                        early_stop_patience=args.patience, trace=trace, lanes_per_chain=args.lanes, rng=args.rng)
     # chains are sharded by contiguous global index; the seed of a chain does not depend on the GPU count
     seeds = abi.seeds_for(base_seed + rank * args.chains, args.chains)
     run = mcq_amd._lib.DeviceRun(p, seeds, trace=trace, states=True)
@@ -187,7 +187,8 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         "config": {
             "workload": f"single_N N={args.N} mcmc_type={args.mcmc_type} init=random {args.schedule} "
                         f"{sp.get('beta_start', sp.get('beta_const'))}->{sp.get('beta_end', '')} "
-                        f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace is True else 'none' if trace is False else 'reduced'}"
+                        + ("" if args.patience is None else f"early_stop_patience={args.patience} ")
+                        + f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace is True else 'none' if trace is False else 'reduced'}"
                         + ("" if args.rng == "mt19937" else f" rng={args.rng} (NOT the reference's stream)"),
             "chains_total": total_chains,
             "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes_n(run.p.mode, run.p.N)),
@@ -225,7 +226,8 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         threads = args.cpu_threads or usable_cpus()
         n_cpu = min(args.cpu_chains, args.chains)
         ctrace = trace is True
-        pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=ctrace, rng=args.rng)
+        pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=ctrace, rng=args.rng,
+                             early_stop_patience=args.patience)
         t1 = time.perf_counter()
         cres = oracle.run(pc, seeds[:n_cpu], trace=ctrace, states=True, n_threads=threads)
         dt = time.perf_counter() - t1
@@ -238,7 +240,8 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
             same = same and bool(np.array_equal(run.t["accept_bits"][:n_cpu].cpu().numpy().view(np.uint64), cres["accept_bits"]))
         del cres
         n_fast = min(8 * n_cpu, args.chains)
-        pf = abi.make_params(args.N, args.n_steps, "random", sp, n_fast, mcmc_type=args.mcmc_type, trace=False, rng=args.rng)
+        pf = abi.make_params(args.N, args.n_steps, "random", sp, n_fast, mcmc_type=args.mcmc_type, trace=False, rng=args.rng,
+                             early_stop_patience=args.patience)
         t2 = time.perf_counter()
         fres = oracle.run(pf, seeds[:n_fast], trace=False, states=False, n_threads=threads, fast=True)
         dt_fast = time.perf_counter() - t2
@@ -339,6 +342,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (4, 8 or 16; 0 = library default)")
     ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
                     help="mt19937 = NumPy's stream (reference-identical, the bench default); philox = counter-based fast mode (evidence only)")
+    ap.add_argument("--patience", type=int, default=None, help="c2 / c3: early_stop_patience (default None = disabled, like config.yaml)")
     ap.add_argument("--no-trace", action="store_true", help="same as --trace none")
     ap.add_argument("--trace", default="i32", choices=["i32", "none", "reduced"],
                     help="c2 / c3: full int32 energy trace (the headline), no trace, or per-step sums accumulated on the device")

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     if constexpr (PHILOX) rng.attach_philox(a.seeds[crow], rec[REC_POS]);
 
     int E = (int)rec[REC_E0];
-    int best = E, no_imp = 0;
+    int best = E;
     // steps_to_best, n_accepted, near ties and the history length change rarely: they live in LDS, not in registers (every lane of
     // a group performs the same read-modify-write in lockstep)
     int* cold = (int*)(base + LDS_COLD);
@@ -921,7 +921,12 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     char* const bits_base = have_bits ? (char*)((uint32_t*)a.out.accept_bits + (long long)blockIdx.x * CPW * a.bits_stride * 2) : nullptr;
     const uint32_t bits_off = (uint32_t)(active ? grp : 0) * (uint32_t)a.bits_stride * 8u;
     auto bits_at = [&](int word) { return (uint32_t*)(bits_base + (bits_off + 4u * (uint32_t)word)); };  // 32-bit word `word` of the chain's row
-    const int patience = a.patience < 0 ? 0x7fffffff : (a.patience > 0x7fffffff ? 0x7fffffff : (int)a.patience);
+    // Early stop (experiments.py:343-353): no_improvement_steps is reset by a strict improvement and grows by one on every other
+    // step, so after step s it equals s - (step of the last improvement, -1 before any): the chain stops at the first step
+    // s >= deadline, deadline = last improvement + patience -- a value that only changes in the (rare) improvement path, so the
+    // common path pays one compare.  A patience beyond n_steps can never trigger and is clamped, which keeps the sum inside 32 bits.
+    const uint32_t patience = a.patience < 0 || a.patience > a.n_steps ? (uint32_t)a.n_steps + 1u : (uint32_t)a.patience;
+    uint32_t deadline = (patience ? patience : 1u) - 1u;  // patience 0 stops at step 0 whatever happens there
 
     if constexpr (REDUCED) {  // stage words carry a `valid` bit (reduce_block): nothing is valid yet, idle groups never are
 #pragma unroll
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     }
 
     // Stream upkeep cadence: demand-driven.  The upkeep code (finish the block in flight, request the next one) runs in a step
-    // when some chain of the wavefront is down to fewer than 28 ready words -- every chain with work pending is served then -- and
+    // when some chain of the wavefront is down to fewer than LOW_WATER ready words -- every chain with work pending is served then -- and
     // is skipped otherwise.  A board step uses 3 (mask + 1) / N + 2 words on average (6.1 at N = 12, 7.7 at N = 17), a full_3d
     // step 8.1, and a block brings 16, so this runs every second or third step with most lanes busy, instead of on a fixed
     // cadence with half of them idle (full_3d +9 %, board N = 17 +10 %, N = 16 +5 %).  The ring can never be overrun: a block
@@ -979,24 +984,33 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
     // at least one step earlier; running dry is handled by the sequential path, which services the stream itself.
     // (PHILOX: the block is generated on the spot, so it needs its room right away: gen - pos <= 48)
     const uint32_t room_limit = PHILOX ? 48u : MODE == MCQ_MODE_BOARD ? 53u : 54u;
-    constexpr uint32_t LOW_WATER = 28;
+    // (A/B on one box, 100 000 steps: board N = 12 low water 16 / 20 / 24 / 28 / 32 / 36 -> 140.3 / 137.1 / 137.4 / 138.3 / 137.9* / 140.5* ms,
+    // N = 24 the same shape; full_3d 20 / 24 / 28 / 32 -> 408.9 / 374.8 / 369.8 / 373.9 ms.  * = another box, shipped 135.4 there.)
+#ifndef MCQ_LOW_WATER
+#define MCQ_LOW_WATER (MODE == MCQ_MODE_BOARD ? 24 : 28)
+#endif
+    constexpr uint32_t LOW_WATER = MCQ_LOW_WATER;
 
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
     int last_entry = n_steps;  // wave-uniform: the last history entry any chain of the wavefront can have reached
-    // Every live lane is at the same step, but where lanes can sit the loop body out (early stopping, the idle groups a
-    // reduced-trace wavefront keeps for its reductions) the compiler no longer sees that and would carry the counter -- and with
-    // it the beta table load and every "every 16 / 32 / 64 steps" test -- in vector registers.  The counter therefore goes through
-    // readfirstlane on its way round the loop: it stays a scalar.
-    constexpr bool SCALAR_STEP = PATIENCE || REDUCED;
-    for (int vstep = 0; vstep < n_steps;) {
+    // One Metropolis step of the wavefront's chains.  Where lanes can sit a step out -- chains that have stopped early, the idle
+    // groups a reduced-trace wavefront keeps for its reductions -- the whole step becomes a divergent region: ~27 scalar and ~11
+    // vector instructions more per step for exec-mask bookkeeping (PMC: 64 / 233 against 38 / 222), and a loop counter the compiler
+    // no longer sees as uniform.  So the step exists twice: ALL = true assumes every lane takes part (no `if (active)`, plain scalar
+    // counter) and runs while that holds -- for the API's default early_stop_patience = 100000 it always does; ALL = false is the
+    // general form, its counter kept scalar through readfirstlane.  Returns STEP_FINISHED when the wavefront has nothing left to do.
+    int vstep = 0;
+    enum { STEP_GO_ON = 0, STEP_FINISHED = 1, STEP_SOMEONE_STOPPED = 2 };
+    auto metropolis_step = [&](auto all_tag) __attribute__((always_inline)) -> int {
+        constexpr bool ALL = decltype(all_tag)::value;
+        bool stopped_now = false;  // ALL: wave-uniform, a chain of the wavefront stopped early in this step
         STAMP(0);  // loop overhead + previous step's tail
-        const int step = SCALAR_STEP ? __builtin_amdgcn_readfirstlane(vstep) : vstep;
+        const int step = ALL ? vstep : __builtin_amdgcn_readfirstlane(vstep);
         vstep = step + 1;
         const float c32 = c32_tab[step];  // exp(-beta dE) = exp2(dE * c32)
-        bool some_stopped = false;        // wave-uniform: a chain of this wavefront stopped early in this step
 
-        if (active) {
+        if (ALL || active) {
             // ---- proposal draws -----------------------------------------------------------------
             // board   (experiments.py:311-327): i, j, new_k (redrawn while == old_k), then random()
             // full_3d (experiments.py:221-239): q, (i, j, k) redrawn while the cell is occupied, random()
@@ -1265,8 +1279,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         const uint32_t Mrc = pk_star2(BB, abs_diff(m, cj) | (abs_diff(m, ci) << 16));
                         const uint32_t Mcc = __builtin_amdgcn_perm(Mrc, Mrc, 0x03020302u);  // the column-distance mask in both halves
                         uint32_t vd, va;  // all ones iff the diagonal / anti-diagonal probe (m, m - ci + cj) / (m, ci + cj - m) is on the board
-                        if constexpr (NT >= 4) {  // four passes: the lane-constant tables would not fit the register file (one spill); compare instead
-                            vd = krc[t] != 0u && (unsigned)(m - ci + cj) < (unsigned)N ? 0xffffffffu : 0u;
+                        if constexpr (NT >= 4) {  // four passes: both lane-constant tables would not fit the register file (one spill): one is a compare instead
+                            vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1);
                             va = krc[t] != 0u && (unsigned)(ci + cj - m) < (unsigned)N ? 0xffffffffu : 0u;
                         } else {
                             vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1), va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1);
@@ -1336,13 +1350,13 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             E += acc ? dE : 0;
             const bool improved = E < best;  // only an accepted move can get below the best so far (E >= best otherwise)
             best = min(best, E);
-            if (PATIENCE) no_imp = improved ? 0 : no_imp + 1;
             const int e = step + 1;
             if (__builtin_expect(wave_any(improved), 0)) {  // rare after the first few hundred steps
                 if (improved) {
                     // first index of the minimum of energy_history (experiments.py:364-365); with patience 0 the chain stops
-                    // right here without appending this entry (no_imp = 0 >= 0), so the index stays
+                    // right here without appending this entry (no_improvement_steps = 0 >= 0), so the index stays
                     if (!PATIENCE || patience > 0) cold[C_BEST_STEP] = e;
+                    if (PATIENCE) deadline = (uint32_t)step + patience;
                     uint8_t* bo = a.out.best_state ? a.out.best_state + chain * (long long)a.state_bytes : nullptr;
                     if (bo) {
                     if (MODE == MCQ_MODE_BOARD) {
@@ -1376,7 +1390,10 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     cold[C_N_ACC] += __popc(accw);  // accepted moves are counted from the bit words
                     if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
                     accw = 0;
-                    if ((step & 63) == 63 && a.pace) {
+#ifndef MCQ_PACE_MASK
+#define MCQ_PACE_MASK 63
+#endif
+                    if ((step & MCQ_PACE_MASK) == MCQ_PACE_MASK && a.pace) {
                         // Pacing: publish this wavefront's progress, read the row of its SIMD, and take a priority that grows with
                         // the number of co-resident wavefronts that are further along (ties fall to the arbiter's age order).
                         const uint32_t mine = (uint32_t)step + 1u;
@@ -1389,9 +1406,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             if constexpr (PATIENCE) {
                 // Early stop (experiments.py:349-353).  A chain stops in few steps of a run, so the test is one wave-wide ballot and
                 // the step's tail runs undivided unless some chain of the wavefront stops right now.
-                const bool stop = no_imp >= patience;
+                const bool stop = (uint32_t)step >= deadline;
                 if (__builtin_expect(wave_any(stop), 0)) {
-                    some_stopped = true;
+                    if constexpr (ALL) stopped_now = true;  // (uniform control flow here: every lane is in this step)
                     if (stop) {
                         // break BEFORE the append: entries 0..step are valid
                         active = false;
@@ -1424,10 +1441,20 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 for (int w = 0; w < WPL; w++) stage[gl * WPL + w] = 0u;
             }
         }
-        if (PATIENCE && some_stopped && !wave_any(active)) {  // (only a step in which a chain stopped can have stopped the last one)
+        if (PATIENCE && (!ALL || stopped_now) && !wave_any(active)) {  // every lane takes part in this ballot, stopped chains included
             last_entry = step + 1;
-            break;
+            return STEP_FINISHED;
         }
+        return ALL && stopped_now ? STEP_SOMEONE_STOPPED : STEP_GO_ON;
+    };
+    if constexpr (PATIENCE || REDUCED) {
+        int r = STEP_GO_ON;
+        if (!wave_any(!active))  // (the last wavefront of a launch may carry idle groups: general form from the start)
+            while (vstep < n_steps && (r = metropolis_step(std::true_type())) == STEP_GO_ON) {}
+        if (r != STEP_FINISHED)
+            while (vstep < n_steps && metropolis_step(std::false_type()) == STEP_GO_ON) {}
+    } else {  // idle groups have left: every lane is a live chain to the end
+        while (vstep < n_steps) (void)metropolis_step(std::true_type());
     }
     STAMP_FLUSH(a.dbg);
     WAVE_T1(a.dbg);
@@ -1613,8 +1640,12 @@ int chain_lds_words_for(int N, int mode, bool narrow) {
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
     // The chains of a wavefront make many accesses at the SAME offset of their slices (history staging, cold scalars, ring appends):
     // a stride of 4 mod 8 words puts the 8 chains of a 32-lane access group on 8 different banks; 0 mod 8 would serialise them
-    // (measured on the headline problem: stride 160 words 142.4 ms, 156 words 134.3 ms).
+    // (A/B on the headline problem, same box: profiles/r02_lds_conflicts.txt).
+#ifdef MCQ_EXP_LDS_STRIDE_0MOD8  // timing experiment (tools/exp_build.sh): the conflicting stride, for the A/B in profiles/
+    w = (w + 7) & ~7;
+#else
     if (w % 8 == 0) w += 4;
+#endif
     return w;
 }
 
@@ -1697,7 +1728,7 @@ int launch_sweep_philox(const KArgs& a, hipStream_t s) {
         }
         return a.red ? launch_sweep<MODE, G, false, 0, true, true>(a, s) : launch_sweep<MODE, G, false, 0, false, true>(a, s);
     } else {
-        const bool pat = a.patience >= 0;
+        const bool pat = a.patience >= 0 && a.patience <= a.n_steps;  // a patience beyond n_steps can never stop a chain: the plain variants give the same results
         if constexpr (G == 4) {
             if (!pat && !a.red && (a.N + 3) / 4 == 3) return launch_sweep<MODE, G, false, 3, false, true>(a, s);
         }
@@ -1730,7 +1761,7 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         }
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     } else {
-        const bool pat = a.patience >= 0;
+        const bool pat = a.patience >= 0 && a.patience <= a.n_steps;  // a patience beyond n_steps can never stop a chain: the plain variants give the same results
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
             // (early stopping -- the reference's default early_stop_patience = 100000 -- has its own unrolled variants for the
             // sizes that default to 4 lanes)
@@ -1741,11 +1772,11 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 default: break;
                 }
             if (!pat) switch ((a.N + G - 1) / G) {
-#define MCQ_NT_CASE(nt) case nt: return a.red ? launch_sweep<MODE, G, false, (nt == 4 ? 0 : nt), true>(a, s) : launch_sweep<MODE, G, false, nt, false>(a, s)
+#define MCQ_NT_CASE(nt) case nt: return a.red ? launch_sweep<MODE, G, false, (nt >= 4 ? 0 : nt), true>(a, s) : launch_sweep<MODE, G, false, nt, false>(a, s)
                 MCQ_NT_CASE(1);  // N = 2..4
                 MCQ_NT_CASE(2);  // N = 5..8
                 MCQ_NT_CASE(3);  // N = 9..12
-                MCQ_NT_CASE(4);  // N = 13..16 (up to here: packed 16-bit masks; the reduced-trace variant would spill and takes the loop)
+                MCQ_NT_CASE(4);  // N = 13..16 (up to here: packed 16-bit masks); from four passes on the reduced-trace variants would spill and take the loop
                 MCQ_NT_CASE(5);  // N = 17..20
                 MCQ_NT_CASE(6);  // N = 21..24
 #undef MCQ_NT_CASE
