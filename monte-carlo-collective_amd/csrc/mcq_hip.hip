@@ -305,10 +305,11 @@ __device__ __forceinline__ uint32_t abs_diff(int a, int b) {
 
 // two distinct cells attack each other iff they share one of the 13 lines: every non-zero
 // coordinate offset has the same magnitude.
+// (branch-free: x is 0 or m iff x (m - x) == 0; coordinates are below 32, so the products fit 24-bit multiplies)
 __device__ __forceinline__ bool on_a_line(int di, int dj, int dk) {
-    di = di < 0 ? -di : di, dj = dj < 0 ? -dj : dj, dk = dk < 0 ? -dk : dk;
-    const int m = max(di, max(dj, dk));
-    return (di == 0 || di == m) && (dj == 0 || dj == m) && (dk == 0 || dk == m);
+    const int a = di < 0 ? -di : di, b = dj < 0 ? -dj : dj, c = dk < 0 ? -dk : dk;
+    const int m = max(a, max(b, c));
+    return (__mul24(a, m - a) | __mul24(b, m - b) | __mul24(c, m - c)) == 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -660,9 +661,12 @@ struct Stream {
         if (HASQ) {
 #pragma unroll
             for (int w = 0; w < WPL; w++) bitsq |= ((t[w] & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
+            const uint32_t both = group_or<G>(bits | (bitsq << 16));
+            set_field(ok_lo, ok_hi, so, both & 0xffffu);
+            set_field(okq_lo, okq_hi, so, both >> 16);
+        } else {
+            set_field(ok_lo, ok_hi, so, group_or<G>(bits));
         }
-        set_field(ok_lo, ok_hi, so, group_or<G>(bits));
-        if (HASQ) set_field(okq_lo, okq_hi, so, group_or<G>(bitsq));
         gen += 16;
     }
 
@@ -707,8 +711,13 @@ struct Stream {
             for (int w = 0; w < WPL; w++) bitsq |= ((t[w] & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
         }
         if (i0 == 0) *word(REC_MIRROR) = v[0];
-        set_field(ok_lo, ok_hi, so, group_or<G>(bits));
-        if (HASQ) set_field(okq_lo, okq_hi, so, group_or<G>(bitsq));
+        if (HASQ) {  // both 16-bit masks through one reduction over the group
+            const uint32_t both = group_or<G>(bits | (bitsq << 16));
+            set_field(ok_lo, ok_hi, so, both & 0xffffu);
+            set_field(okq_lo, okq_hi, so, both >> 16);
+        } else {
+            set_field(ok_lo, ok_hi, so, group_or<G>(bits));
+        }
         gen += 16;
         gi = gi + 16 == MT_N ? 0 : gi + 16;
         pending = false;
@@ -1160,8 +1169,9 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 oldp = qn[qi];
                 const int i1 = (int)(w1 & maskN), j1 = (int)(w2 & maskN), k1 = (int)(w3 & maskN) & 31;
                 const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
-                const bool free1 = !((colw[__mul24(i1, N) + j1] >> k1) & 1u);  // word index < 2^10: inside the workgroup's LDS
-                const bool free2 = !((colw[__mul24(i2, N) + j2] >> k2) & 1u);
+                uint32_t cw1 = colw[__mul24(i1, N) + j1], cw2 = colw[__mul24(i2, N) + j2];  // word index < 2^10: inside the workgroup's LDS
+                asm volatile("" : "+v"(cw1), "+v"(cw2));  // both reads in flight together: one LDS round trip, not one after the other
+                const bool free1 = !((cw1 >> k1) & 1u), free2 = !((cw2 >> k2) & 1u);
                 pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
                 uw1 = free1 ? u31 : u61, uw2 = free1 ? u32 : u62;
                 batched = view_ok && (free1 || free2);
@@ -1178,6 +1188,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             // ---- dE -------------------------------------------------------------------------------
             int dE;
             uint32_t newp = 0;
+            uint32_t cw_new = 0, cw_old = 0;  // full_3d: occupancy words of the new and of the old cell's column
             if (MODE == MCQ_MODE_BOARD) {
                 // dE = conflicts(new_k) - conflicts(old_k) (mcmc_board.py:147-193).  Probe the columns on the
                 // four lines of the ij-plane through (i, j).  Column (i2, j2) at distance d holds height h; it
@@ -1278,13 +1289,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                         const uint32_t wr = crow[m], wc = cw[cj], wd = cw[m - ci + cj], wa = cw[ci + cj - m];
                         const uint32_t Mrc = pk_star2(BB, abs_diff(m, cj) | (abs_diff(m, ci) << 16));
                         const uint32_t Mcc = __builtin_amdgcn_perm(Mrc, Mrc, 0x03020302u);  // the column-distance mask in both halves
-                        uint32_t vd, va;  // all ones iff the diagonal / anti-diagonal probe (m, m - ci + cj) / (m, ci + cj - m) is on the board
-                        if constexpr (NT >= 4) {  // four passes: both lane-constant tables would not fit the register file (one spill): one is a compare instead
-                            vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1);
-                            va = krc[t] != 0u && (unsigned)(ci + cj - m) < (unsigned)N ? 0xffffffffu : 0u;
-                        } else {
-                            vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1), va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1);
-                        }
+                        const uint32_t vd = (uint32_t)__builtin_amdgcn_sbfe((int)vdm[t], shd, 1), va = (uint32_t)__builtin_amdgcn_sbfe((int)vam[t], sha, 1);
                         cnt += __popc((wr | (wc << 16)) & Mrc & krc[t]);
                         cnt += __popc(((wd & vd) | ((wa & va) << 16)) & Mcc);
                     }
@@ -1304,7 +1309,8 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                 // side, i.e. +4.  Own columns (the k-axis lines): popc(W) minus the moving queen on the old side.  On the
                 // new side the moving queen still sits at the old cell; if that lies on a line through the new cell it was
                 // counted and is removed.
-                const int own_new = __popc(colw[__mul24(ni, N) + nj]), own_old = __popc(colw[__mul24(oi, N) + oj]) - 1;
+                cw_new = colw[__mul24(ni, N) + nj], cw_old = colw[__mul24(oi, N) + oj];  // kept: an accepted move rewrites them without reading again
+                const int own_new = __popc(cw_new), own_old = __popc(cw_old) - 1;
                 const int moving = on_a_line(oi - ni, oj - nj, ok_ - nk) ? 1 : 0;
                 dE = group_sum<G>(part) + 4 + own_new - own_old - moving;
             }
@@ -1340,11 +1346,14 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
             if (MODE == MCQ_MODE_BOARD) {
                 hts[cell] = (uint8_t)(acc ? pc : old_k);  // every lane of the group writes the same byte; a rejected move rewrites the old height
             } else if (acc) {
-                // mcmc.py:171-183; every lane of the group performs the same read-modify-writes
-                colw_t* wo = colw + __mul24((int)(oldp & 31), N) + (int)((oldp >> 5) & 31);
-                *wo = (colw_t)(*wo & ~(1u << ((oldp >> 10) & 31)));
-                colw_t* wn = colw + __mul24(pa, N) + pb;
-                *wn = (colw_t)(*wn | (1u << pc));
+                // mcmc.py:171-183; every lane of the group performs the same writes.  The two column words were read for the own-column
+                // counts of dE: no second LDS round trip here.  A move inside one column changes one word twice: the second
+                // store carries both changes (LDS stores of a wavefront land in order).
+                const uint32_t op_i = oldp & 31, op_j = (oldp >> 5) & 31;
+                const uint32_t cleared = cw_old & ~(1u << ((oldp >> 10) & 31));
+                const bool same_column = op_i == (uint32_t)pa && op_j == (uint32_t)pb;
+                colw[__mul24((int)op_i, N) + (int)op_j] = (colw_t)cleared;
+                colw[__mul24(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | (1u << pc));
                 qn[qi] = (uint16_t)newp;
             }
             E += acc ? dE : 0;
