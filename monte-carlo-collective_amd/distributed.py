@@ -6,8 +6,8 @@ of GPUs and there is no data-path collective.  The only exchange is at the end o
 all-reduce (SUM, int64) of one packed tensor over the default process group (RCCL over xGMI on a GPU node:
 backend "nccl"; gloo on CPU for the tests):
 
-    per job   7 counters                      n_chains, accepted, proposed, sum / sum of squares of best_energy,
-                                              sum / sum of squares of steps_to_best
+    per job   6 counters                      n_chains, accepted, proposed, sum / sum of squares of best_energy,
+                                              sum of steps_to_best
               `world` slots                   rank r writes its local minimum of best_energy (+1) into slot r and zeros
                                               elsewhere: the SUM then holds every rank's minimum and the node-level MIN is a
                                               local min over the slots -- no second collective with another reduce op
@@ -20,12 +20,14 @@ backend "nccl"; gloo on CPU for the tests):
 The tensor lives where the results live (HBM for the GPU path), so nothing is staged through the host before the
 collective.
 """
+import math
+
 import numpy as np
 
 from . import abi
 
-N_COUNTERS = 7
-COUNTER_FIELDS = ("n_chains", "accepted", "proposed", "sum_best", "sumsq_best", "sum_steps_to_best", "sumsq_steps_to_best")
+N_COUNTERS = 6
+COUNTER_FIELDS = ("n_chains", "accepted", "proposed", "sum_best", "sumsq_best", "sum_steps_to_best")
 STAT_FIELDS = ("step_sum", "step_sumsq", "step_accepted", "step_count", "step_stopped")
 
 
@@ -87,7 +89,6 @@ def pack_job(buf, lay, rank, lo, res, torch):
         c[3] = best.sum()
         c[4] = (best * best).sum()
         c[5] = stb.sum()
-        c[6] = (stb * stb).sum()
         buf[lay.mins + rank] = best.min() + 1  # 0 = "this rank has no chain of the job"
         if lay.per_chain:
             buf[lay.best + lo:lay.best + lo + n] = best
@@ -113,9 +114,8 @@ def summary_from_counters(counters, mins):
     out["min_best"] = min(present) if present else None
     out["mean_best"] = out["sum_best"] / n
     # population std, as np.std (experiments.py:1080), from exact integers
-    out["std_best"] = float(np.sqrt(max(0, n * out["sumsq_best"] - out["sum_best"] ** 2))) / n
+    out["std_best"] = math.sqrt(max(0, n * out["sumsq_best"] - out["sum_best"] ** 2)) / n  # exact Python integers under the root
     out["mean_steps_to_best"] = out["sum_steps_to_best"] / n
-    out["std_steps_to_best"] = float(np.sqrt(max(0, n * out["sumsq_steps_to_best"] - out["sum_steps_to_best"] ** 2))) / n
     out["acceptance_rate"] = out["accepted"] / max(1, out["proposed"])
     return out
 

@@ -71,3 +71,13 @@ def test_two_gloo_ranks_equal_one_process():
     assert (got[0][1], got[0][2], got[1][1], got[1][2]) == (0, 19, 19, 37)
     assert summary["n_chains"] == 37 and summary["proposed"] == 37 * 600
     assert summary["min_best"] == min(best) and abs(summary["std_best"] - float(np.std(best))) < 1e-9
+
+
+def test_summary_arithmetic_survives_large_counts():
+    """10^6-step runs of 65 536 chains: n * sum(x^2) exceeds 2^63 -- the variance is taken from Python integers."""
+    n, best = 65536, 30
+    c = np.array([n, 10**12, n * 10**6, n * best, n * best * best + 4 * n, n * 900000], dtype=np.int64)
+    s = dm.summary_from_counters(c, np.array([26, 0], dtype=np.int64))
+    assert s["min_best"] == 25 and s["mean_best"] == best and abs(s["std_best"] - 2.0) < 1e-12 and s["mean_steps_to_best"] == 900000
+    huge = np.array([2**31 - 1, 0, 0, (2**31 - 1) * 14000, (2**31 - 1) * 14000**2, 0], dtype=np.int64)
+    assert dm.summary_from_counters(huge, np.array([1], dtype=np.int64))["std_best"] == 0.0

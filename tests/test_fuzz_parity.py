@@ -54,3 +54,61 @@ def test_random_parameter_sets():
         got, _ = mcq_amd._lib.run_host(p, seeds)
         util.assert_results_equal(got, want, what)
         assert got["near_ties"].sum() == 0, what
+
+
+def _feature_cases(n=160):
+    rng = np.random.default_rng(77001)
+    scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
+
+    def sched():
+        st = str(rng.choice(scheds))
+        if st == "constant":
+            return {"type": st, "beta_const": float(rng.choice([0.3, 1.0, 2.5]))}
+        return {"type": st, "beta_start": float(rng.choice([0.1, 0.5, 1.0])), "beta_end": float(rng.choice([2.0, 3.0, 6.0]))}
+
+    out = []
+    for c in range(n):
+        mode = "board" if rng.random() < 0.55 else "full_3d"
+        N = int(rng.choice([2, 3, 5, 6, 8, 9, 12, 13, 16, 17, 20, 24]))
+        if mode == "full_3d" and N > 17:
+            N = int(rng.integers(2, 18))
+        n_steps = int(rng.choice([0, 1, 15, 16, 17, 33, 64, 100, 300]))
+        patience = int(rng.choice([0, 3, 25, 120])) if mode == "board" and rng.random() < 0.4 else None
+        n_sets = int(rng.choice([1, 1, 2, 3]))
+        cps = 16 * int(rng.integers(1, 3)) if n_sets > 1 else int(rng.choice([1, 3, 16, 19]))
+        sets = [sched() for _ in range(n_sets)]
+        inits = [str(rng.choice(["random", "latin", "klarner"])) for _ in range(n_sets)]
+        out.append(dict(c=c, N=N, mode=mode, n_steps=n_steps, patience=patience, sets=sets, inits=inits, cps=cps,
+                        rng="philox" if rng.random() < 0.5 else "mt19937", reduced=bool(rng.random() < 0.5),
+                        lanes=int(rng.choice([0, 4, 8, 16])), seed0=int(rng.integers(0, 2**31))))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_random_feature_combinations():
+    """The round-2 features crossed at random: Philox stream, reduced trace (against the sums of the oracle's full trace, early
+    stops included), schedule sets with their own init modes, every lane width."""
+    for k in _feature_cases():
+        what = str(k)
+        if len(k["sets"]) > 1:
+            p = abi.make_params_sets(k["N"], k["n_steps"], k["inits"][0], k["sets"], k["cps"], mcmc_type=k["mode"], early_stop_patience=k["patience"],
+                                     lanes_per_chain=k["lanes"], rng=k["rng"], init_modes=k["inits"])
+            seeds = np.concatenate([abi.seeds_for(k["seed0"] + 1000 * t, k["cps"]) for t in range(len(k["sets"]))])
+        else:
+            p = abi.make_params(k["N"], k["n_steps"], k["inits"][0], k["sets"][0], k["cps"], mcmc_type=k["mode"], early_stop_patience=k["patience"],
+                                lanes_per_chain=k["lanes"], rng=k["rng"])
+            seeds = abi.seeds_for(k["seed0"], k["cps"])
+        want = oracle.run(p, seeds, n_threads=8)
+        if not k["reduced"]:
+            got, _ = mcq_amd._lib.run_host(p, seeds)
+            util.assert_results_equal(got, want, what)
+            continue
+        got, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced")
+        util.assert_results_equal(got, want, what, trace=False)
+        for t in range(len(k["sets"])):
+            sl = slice(t * k["cps"], (t + 1) * k["cps"])
+            st = mcq_amd.jobs.stats_from_trace({f: v[sl] for f, v in want.items()}, k["n_steps"])
+            for f in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+                g = got[f][t] if len(k["sets"]) > 1 else got[f]
+                np.testing.assert_array_equal(g, st[f], err_msg=f"{what}: {f} of set {t}")

@@ -173,7 +173,7 @@ def test_one_packed_collective(monkeypatch):
     jobs = [mcq_amd.jobs.make_job(5, 100, "random", {"type": "constant", "beta_const": 1.0}, 10, 42 + 1000 * i, "board", None) for i in range(4)]
     out = mcq_amd.jobs.JobSet(jobs, want="stats", dist=FakeDist, runner=oracle_runner).run()
     assert len(calls) == 1 and calls[0][1] == "sum"
-    assert calls[0][0] == (4 * (7 + 2 + 2 * 10 + 5 * 101),)
+    assert calls[0][0] == (4 * (6 + 2 + 2 * 10 + 5 * 101),)
     assert all(o["summary"]["n_chains"] == 5 for o in out)  # rank 0 of 2 ran chains [0, 5) of every job; the fake reduce adds nothing
 
 
