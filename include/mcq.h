@@ -139,8 +139,8 @@ typedef struct mcq_outputs {
     int64_t* steps_to_best;  /* [n_chains] first index of min(energy_history) (experiments.py:364-365) */
     int64_t* n_accepted;     /* [n_chains] */
     int64_t* near_ties;      /* optional [n_chains]: steps whose uniform fell within 4 ulp of the acceptance probability */
-    uint8_t* best_state;     /* optional [n_chains][state_bytes] */
-    uint8_t* final_state;    /* optional [n_chains][state_bytes] */
+    uint8_t* best_state;     /* optional [n_chains][state_bytes]; HIP: 16-byte aligned base (rows are copied 16 bytes at a time) */
+    uint8_t* final_state;    /* optional [n_chains][state_bytes]; HIP: 16-byte aligned base */
     /* trace == REDUCED only, int64[n_steps + 1] each (per schedule set: [n_sets][n_steps + 1]), indexed by history entry e
      * (entry 0 = initial state): */
     int64_t* step_sum;       /* sum over chains of energy_history[e]                                   */

@@ -842,6 +842,61 @@ __global__ __launch_bounds__(256) void mcq_reduced_finalize_kernel(const unsigne
     sum[e] = (long long)t[0], sumsq[e] = (long long)t[1], accepted[e] = (long long)(t[2] & 0xffffffffull), count[e] = (long long)(t[2] >> 32);
 }
 
+// A chain's state to the caller's best_state / final_state row, by the G lanes of its group.  A strict improvement copies the
+// board (experiments.py:340-343 `best_state = state.copy()`): ~400 times per chain in a 10^5-step run and 1 600 times at N = 24,
+// and with 8 or 16 chains per wavefront some chain improves in every tenth step -- byte stores made that loop 29 % of an N = 24
+// step (`apply+history`, profiles/r02_stamp_shares.txt).  Rows are 16-byte aligned whenever Q % 16 == 0 (the host side checks the
+// base), so the copy moves 16 bytes per lane and instruction; odd sizes fall back to dwords or bytes.
+template <int G>
+__device__ __forceinline__ void copy_board_out(uint8_t* dst, const uint8_t* hts, int Q, int gl) {
+    if ((Q & 15) == 0) {
+        for (int c = gl; c < (Q >> 4); c += G) ((uint4*)dst)[c] = ((const uint4*)hts)[c];
+    } else if ((Q & 3) == 0) {
+        for (int c = gl; c < (Q >> 2); c += G) ((uint32_t*)dst)[c] = ((const uint32_t*)hts)[c];
+    } else {
+        for (int c = gl; c < Q; c += G) dst[c] = hts[c];
+    }
+}
+// full_3d: queens are packed i | j << 5 | k << 10 in LDS and (i, j, k) bytes in the caller's row: four queens = three dwords
+template <int G>
+__device__ __forceinline__ void copy_queens_out(uint8_t* dst, const uint16_t* qn, int Q, int gl) {
+    if ((Q & 3) == 0) {
+        for (int c = gl; c < (Q >> 2); c += G) {
+            const uint2 p = *(const uint2*)(qn + 4 * c);  // queens 4c .. 4c+3
+            const uint32_t q0 = p.x & 0xffffu, q1 = p.x >> 16, q2 = p.y & 0xffffu, q3 = p.y >> 16;
+            auto I = [](uint32_t q) { return q & 31u; };
+            auto J = [](uint32_t q) { return (q >> 5) & 31u; };
+            auto K = [](uint32_t q) { return (q >> 10) & 31u; };
+            uint32_t* d = (uint32_t*)(dst + 12 * c);
+            d[0] = I(q0) | (J(q0) << 8) | (K(q0) << 16) | (I(q1) << 24);
+            d[1] = J(q1) | (K(q1) << 8) | (I(q2) << 16) | (J(q2) << 24);
+            d[2] = K(q2) | (I(q3) << 8) | (J(q3) << 16) | (K(q3) << 24);
+        }
+    } else {
+        for (int c = gl; c < Q; c += G) {
+            const uint32_t pq = qn[c];
+            dst[3 * c] = (uint8_t)(pq & 31), dst[3 * c + 1] = (uint8_t)((pq >> 5) & 31), dst[3 * c + 2] = (uint8_t)((pq >> 10) & 31);
+        }
+    }
+}
+
+// The same as real calls: the kernels whose step exists twice (early stop, reduced trace) would otherwise carry four inlined
+// copies of these loops and spill; a call in the rare improvement path costs them nothing measurable and frees ~15 VGPRs.
+template <int G>
+__device__ __attribute__((noinline)) void copy_board_out_call(uint8_t* dst, const uint8_t* hts, int Q, int gl) { copy_board_out<G>(dst, hts, Q, gl); }
+template <int G>
+__device__ __attribute__((noinline)) void copy_queens_out_call(uint8_t* dst, const uint16_t* qn, int Q, int gl) { copy_queens_out<G>(dst, qn, Q, gl); }
+template <int MODE, int G, bool CALL>
+__device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts, const uint16_t* qn, int Q, int gl) {
+    if constexpr (MODE == MCQ_MODE_BOARD) {
+        if constexpr (CALL) copy_board_out_call<G>(dst, hts, Q, gl);
+        else copy_board_out<G>(dst, hts, Q, gl);
+    } else {
+        if constexpr (CALL) copy_queens_out_call<G>(dst, qn, Q, gl);
+        else copy_queens_out<G>(dst, qn, Q, gl);
+    }
+}
+
 // NT > 0: ceil(N / G) is a compile-time constant, so the dE probes of a step are issued as one straight-line block
 // (all their LDS reads in flight together); NT == 0: run-time loop over the probe passes.
 // REDUCED: trace == MCQ_TRACE_REDUCED (per-entry sums accumulated in the sweep); a separate instantiation so that the
@@ -1367,16 +1422,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
                     if (!PATIENCE || patience > 0) cold[C_BEST_STEP] = e;
                     if (PATIENCE) deadline = (uint32_t)step + patience;
                     uint8_t* bo = a.out.best_state ? a.out.best_state + chain * (long long)a.state_bytes : nullptr;
-                    if (bo) {
-                    if (MODE == MCQ_MODE_BOARD) {
-                        for (int c = gl; c < Q; c += G) bo[c] = hts[c];
-                    } else {
-                        for (int c = gl; c < Q; c += G) {
-                            const uint32_t pq = qn[c];
-                            bo[3 * c] = (uint8_t)(pq & 31), bo[3 * c + 1] = (uint8_t)((pq >> 5) & 31), bo[3 * c + 2] = (uint8_t)((pq >> 10) & 31);
-                        }
-                    }
-                    }
+                    if (bo) copy_state_out<MODE, G, PATIENCE || REDUCED>(bo, hts, qn, Q, gl);
                 }
             }
 
@@ -1497,14 +1543,7 @@ __global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
         }
         if (a.out.final_state) {
             uint8_t* fo = a.out.final_state + chain * (long long)a.state_bytes;
-            if (MODE == MCQ_MODE_BOARD) {
-                for (int c = gl; c < Q; c += G) fo[c] = hts[c];
-            } else {
-                for (int c = gl; c < Q; c += G) {
-                    const uint32_t pq = qn[c];
-                    fo[3 * c] = (uint8_t)(pq & 31), fo[3 * c + 1] = (uint8_t)((pq >> 5) & 31), fo[3 * c + 2] = (uint8_t)((pq >> 10) & 31);
-                }
-            }
+            copy_state_out<MODE, G, PATIENCE || REDUCED>(fo, hts, qn, Q, gl);
         }
     }
 }
@@ -1820,6 +1859,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     if (workspace_bytes < mcq_workspace_bytes(p)) return fail(MCQ_ENOMEM, "workspace too small");
     // the sweep reads the MT words of a record with 16-byte loads and flushes the trace in aligned 64-byte segments
     if (((uintptr_t)workspace & 63u) != 0) return fail(MCQ_EINVAL, "workspace must be 64-byte aligned");
+    if ((((uintptr_t)out->best_state | (uintptr_t)out->final_state) & 15u) != 0) return fail(MCQ_EINVAL, "best_state / final_state must be 16-byte aligned");
     if (p->trace == MCQ_TRACE_I32) {
         if (!out->energy_hist || !out->accept_bits) return fail(MCQ_EINVAL, "trace requested without buffers");
         if (p->hist_stride < p->n_steps + 1) return fail(MCQ_EINVAL, "hist_stride too small");
