@@ -210,6 +210,8 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         },
     }
     if pmc:
+        if algo_bytes:
+            line["roofline"]["traffic_ratio"] = pmc["bytes_per_launch"] / algo_bytes  # measured fabric bytes over algorithmic bytes
         line["roofline"]["traffic_source"] = {k: pmc[k] for k in ("kernel_sha256", "commit", "read_bytes", "write_bytes", "l2_hit_rate") if k in pmc}
         if pmc.get("valu_insts_per_launch"):
             # the on-chip view of the same kernel: wave64 VALU instructions (PMC count of this workload) over the live kernel

@@ -254,8 +254,9 @@ def mean_std_from_sums(step_sum, step_sumsq, step_count):
     n = np.asarray(step_count, dtype=np.int64)
     with np.errstate(invalid="ignore", divide="ignore"):
         mean = s / n
-    num = np.array([int(ni) * int(qi) - int(si) * int(si) for ni, qi, si in zip(n, q, s)], dtype=object)
-    var = np.array([float(v) / (int(ni) * int(ni)) if int(ni) else np.nan for v, ni in zip(num, n)], dtype=np.float64)
+    no, qo, so = n.astype(object), q.astype(object), s.astype(object)  # Python integers: n * sum(x^2) passes 2^63 at BASELINE sizes
+    num, den = no * qo - so * so, no * no
+    var = np.array([v / d if d else np.nan for v, d in zip(num, den)], dtype=np.float64)  # int / int: correctly rounded
     return mean, np.sqrt(np.maximum(var, 0.0))
 
 
