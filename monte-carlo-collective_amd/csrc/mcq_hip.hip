@@ -902,8 +902,10 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // REDUCED: trace == MCQ_TRACE_REDUCED (per-entry sums accumulated in the sweep); a separate instantiation so that the
 // default kernels carry none of its code.
 // PHILOX: mcq_params.rng == MCQ_RNG_PHILOX4X32_10 (the stream is computed, not read from the chain record).
+// (full_3d at 4 lanes per chain, unrolled: 16 chains of 1 KB per wavefront leave room for 2-3 wavefronts per SIMD, so that variant may
+// use the registers of a 2-per-SIMD kernel)
 template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false>
-__global__ __launch_bounds__(64, 4) void mcq_sweep_kernel(KArgs a) {
+__global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : 4) void mcq_sweep_kernel(KArgs a) {
     WAVE_T0;
     // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
     const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);
@@ -1807,6 +1809,15 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 }
             }
         }
+#ifdef MCQ_EXP_F3D_G4
+        if constexpr (G == 4) {  // experiment: the 16-bit layout with two lanes around each of the two cells, six unrolled passes
+            if (!a.red && (a.N + 1) / 2 == 6) {
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+                return launch_sweep<MODE, G, false, 6, false>(b, s);
+            }
+        }
+#endif
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     } else {
         const bool pat = a.patience >= 0 && a.patience <= a.n_steps;  // a patience beyond n_steps can never stop a chain: the plain variants give the same results
