@@ -34,8 +34,8 @@ def main():
         if os.path.exists(os.path.join(ev, a)):
             shutil.copy(os.path.join(ev, a), os.path.join(prof, b))
     ks = glob.glob(os.path.join(ev, "kernel_stats", "**", "*kernel_stats.csv"), recursive=True)
-    if ks:
-        shutil.copy(ks[0], os.path.join(prof, f"{r}_kernel_stats.csv"))
+    if ks:  # gpurun merges every session into the same directory: take the newest trace
+        shutil.copy(max(ks, key=os.path.getmtime), os.path.join(prof, f"{r}_kernel_stats.csv"))
     with open(os.path.join(prof, f"{r}_registers.txt"), "w") as f:
         f.write(run("tools/register_table.py"))
     # the Philox evidence in one place: bench line + counters
