@@ -1067,14 +1067,27 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     // counter) and runs while that holds -- for the API's default early_stop_patience = 100000 it always does; ALL = false is the
     // general form, its counter kept scalar through readfirstlane.  Returns STEP_FINISHED when the wavefront has nothing left to do.
     int vstep = 0;
-    enum { STEP_GO_ON = 0, STEP_FINISHED = 1, STEP_SOMEONE_STOPPED = 2 };
+    enum { STEP_GO_ON = 0, STEP_FINISHED = 1 };
     auto metropolis_step = [&](auto all_tag) __attribute__((always_inline)) -> int {
         constexpr bool ALL = decltype(all_tag)::value;
-        bool stopped_now = false;  // ALL: wave-uniform, a chain of the wavefront stopped early in this step
         STAMP(0);  // loop overhead + previous step's tail
         const int step = ALL ? vstep : __builtin_amdgcn_readfirstlane(vstep);
         vstep = step + 1;
         const float c32 = c32_tab[step];  // exp(-beta dE) = exp2(dE * c32)
+        // what closes a step for the whole wavefront (stopped and idle lanes included): REDUCED adds every 16th block of entries
+        // to the accumulators.  SOME_INACTIVE = false: every lane is a live chain (the ALL form's common path).
+        auto end_of_step = [&](auto some_inactive) __attribute__((always_inline)) {
+            STAMP(5);  // apply + history
+            if (reduced && ((step + 1) & 15) == 15) {
+                reduce_block<G>(lds + LDS_STAGE, a.chain_lds_words, lane, (step + 1) & ~15, a.n_steps + 1, red, a.red_len);
+                if constexpr (decltype(some_inactive)::value) {
+                    if (!active) {  // a stopped (or idle) chain's block must not be counted again
+#pragma unroll
+                        for (int w = 0; w < WPL; w++) stage[gl * WPL + w] = 0u;
+                    }
+                }
+            }
+        };
 
         if (ALL || active) {
             // ---- proposal draws -----------------------------------------------------------------
@@ -1460,12 +1473,12 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     }
                 }
             };
-            if constexpr (PATIENCE) {
+            if constexpr (PATIENCE && !ALL) {
                 // Early stop (experiments.py:349-353).  A chain stops in few steps of a run, so the test is one wave-wide ballot and
-                // the step's tail runs undivided unless some chain of the wavefront stops right now.
+                // the step's tail runs undivided unless some chain of the wavefront stops right now.  (The ALL form never gets here with
+                // a chain that stops: its loop hands a step in which one might over to this form before executing it.)
                 const bool stop = (uint32_t)step >= deadline;
                 if (__builtin_expect(wave_any(stop), 0)) {
-                    if constexpr (ALL) stopped_now = true;  // (uniform control flow here: every lane is in this step)
                     if (stop) {
                         // break BEFORE the append: entries 0..step are valid
                         active = false;
@@ -1490,26 +1503,32 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 append_entry();
             }
         }
-        STAMP(5);  // apply + history
-        if (reduced && ((step + 1) & 15) == 15) {
-            reduce_block<G>(lds + LDS_STAGE, a.chain_lds_words, lane, (step + 1) & ~15, a.n_steps + 1, red, a.red_len);
-            if (!active) {  // a stopped (or idle) chain's block must not be counted again
-#pragma unroll
-                for (int w = 0; w < WPL; w++) stage[gl * WPL + w] = 0u;
+        end_of_step(std::integral_constant<bool, !ALL>());
+        if constexpr (PATIENCE && !ALL) {
+            if (!wave_any(active)) {  // every lane takes part in this ballot, stopped chains included
+                last_entry = step + 1;
+                return STEP_FINISHED;
             }
         }
-        if (PATIENCE && (!ALL || stopped_now) && !wave_any(active)) {  // every lane takes part in this ballot, stopped chains included
-            last_entry = step + 1;
-            return STEP_FINISHED;
-        }
-        return ALL && stopped_now ? STEP_SOMEONE_STOPPED : STEP_GO_ON;
+        return STEP_GO_ON;
     };
     if constexpr (PATIENCE || REDUCED) {
-        int r = STEP_GO_ON;
+        // The ALL form runs while every lane is a live chain and none can stop in the step at hand: a chain stops at the first step
+        // >= its deadline, and a step can only move the deadline further away (an improvement), so `step >= deadline` before the step
+        // is the condition -- or a false alarm, which costs one step in the general form.  That step and everything after it goes to
+        // the general form: the ALL form holds no early-stop code at all, only this compare in front of each step.
         if (!wave_any(!active))  // (the last wavefront of a launch may carry idle groups: general form from the start)
-            while (vstep < n_steps && (r = metropolis_step(std::true_type())) == STEP_GO_ON) {}
-        if (r != STEP_FINISHED)
-            while (vstep < n_steps && metropolis_step(std::false_type()) == STEP_GO_ON) {}
+        {
+            // (one condition, evaluated without a short circuit, and one exit at the bottom: with two exits the compiler carries shadow
+            // copies of the per-lane flags it keeps in scalar registers -- eight scalar instructions per step)
+            auto all_go_on = [&]() { return ((vstep < n_steps ? 1 : 0) & (PATIENCE && wave_any((uint32_t)vstep >= deadline) ? 0 : 1)) != 0; };
+            if (all_go_on()) {  // written as a guarded do-while: the ballot is a convergent operation, which the compiler will not duplicate to rotate a while loop
+                do {
+                    (void)metropolis_step(std::true_type());
+                } while (all_go_on());
+            }
+        }
+        while (vstep < n_steps && metropolis_step(std::false_type()) == STEP_GO_ON) {}
     } else {  // idle groups have left: every lane is a live chain to the end
         while (vstep < n_steps) (void)metropolis_step(std::true_type());
     }
