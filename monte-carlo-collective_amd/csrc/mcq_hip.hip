@@ -904,7 +904,10 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // PHILOX: mcq_params.rng == MCQ_RNG_PHILOX4X32_10 (the stream is computed, not read from the chain record).
 // (full_3d at 4 lanes per chain, unrolled: 16 chains of 1 KB per wavefront leave room for 2-3 wavefronts per SIMD, so that variant may
 // use the registers of a 2-per-SIMD kernel)
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false>
+// NC: the board size as a compile-time constant (0: taken from the arguments).  The probe addresses of the later passes are the
+// first pass's plus multiples of N: with N known they become immediate offsets of the LDS reads instead of an addition each
+// (12 vector instructions of ~208 per step on the headline problem); instantiated for N = 12, the size of BASELINE configs 2 and 3.
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0>
 __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : 4) void mcq_sweep_kernel(KArgs a) {
     WAVE_T0;
     // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
@@ -918,7 +921,9 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     const int lane = threadIdx.x;
     const int gl = lane & (G - 1), grp = lane / G;
     const long long chain = (long long)blockIdx.x * CPW + grp;
-    const int N = a.N, Q = a.Q;
+    const int N = NC ? NC : a.N, Q = NC ? NC * NC : a.Q;
+    const int full_pad = NC ? (NC + 3) & ~3 : a.full_pad;
+    const int state_bytes = NC ? (MODE == MCQ_MODE_BOARD ? NC * NC : 3 * NC * NC) : a.state_bytes;
     bool active = chain < a.n_chains;
     constexpr bool reduced = REDUCED;
     if (!PATIENCE && !active && !reduced) return;  // no wave-wide operation below: idle groups of the last wavefront can leave
@@ -934,8 +939,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
     constexpr bool NARROW = MODE == MCQ_MODE_FULL3D && NT > 0;  // N <= 16: 16-bit column words
     typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type colw_t;
-    colw_t* colw = (colw_t*)(base + LDS_STATE) + a.full_pad;
-    uint16_t* qn = (uint16_t*)(colw + Q + a.full_pad);
+    colw_t* colw = (colw_t*)(base + LDS_STATE) + full_pad;
+    uint16_t* qn = (uint16_t*)(colw + Q + full_pad);
 
     // ---- load the chain record ----
     uint32_t* rec = a.ws + crow * (long long)a.rec_words;
@@ -944,18 +949,18 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
     } else {
         uint32_t* cw32 = base + LDS_STATE;  // the column table and its pads as 32-bit words
-        const int cwords = (int)((2 * a.full_pad + Q) * sizeof(colw_t) / 4);
+        const int cwords = (int)((2 * full_pad + Q) * sizeof(colw_t) / 4);
         for (int w = gl; w < cwords; w += G) cw32[w] = 0;
         for (int c = gl; c < Q; c += G) {
             const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
             qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
-            const uint32_t e = (uint32_t)a.full_pad + qi_ * N + qj_;  // element index from the start of the table
+            const uint32_t e = (uint32_t)full_pad + qi_ * N + qj_;  // element index from the start of the table
             if (NARROW) atomicOr(&cw32[e >> 1], (1u << qk_) << ((e & 1u) * 16u));
             else atomicOr(&cw32[e], 1u << qk_);
         }
     }
     const unsigned mN = (unsigned)(N - 1), mQ = (unsigned)(Q - 1);
-    const unsigned maskN = a.maskN, maskQ = a.maskQ;
+    const unsigned maskN = NC ? mask_for((unsigned)(NC - 1)) : a.maskN, maskQ = NC ? mask_for((unsigned)(NC * NC - 1)) : a.maskQ;
     uint32_t tc1 = 0x9d2c5680u, tc2 = 0xefc60000u;
     asm volatile("" : "+s"(tc1), "+s"(tc2));  // opaque scalars: no literal operands in the tempering
     const uint32_t rec_bytes = (uint32_t)a.rec_words * 4u;
@@ -1004,8 +1009,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     if (active) {
         if (gl == 0 && a.out.initial_energy) a.out.initial_energy[chain] = E;
         if (a.out.best_state) {
-            uint8_t* bo = a.out.best_state + crow * (long long)a.state_bytes;
-            for (int c = gl; c < a.state_bytes; c += G) bo[c] = rst[c];
+            uint8_t* bo = a.out.best_state + crow * (long long)state_bytes;
+            for (int c = gl; c < state_bytes; c += G) bo[c] = rst[c];
         }
     }
 
@@ -1033,7 +1038,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     for (int t = 0; t < NTP; t++) {
         const int m = (gl & (PG - 1)) + t * PG;
         // only the last pass can leave the board: a variant with NT passes runs for ceil(N / PG) == NT, i.e. N > (NT - 1) * PG
-        const bool inb = t + 1 < NTP || m < N;
+        const bool inb = t + 1 < NTP || (NC != 0 && NTP * PG <= NC) || m < N;
         const uint32_t full = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
         pm[t] = inb ? m : N - 1;
         krc[t] = inb ? (NARROW ? 0xffffffffu : 0x00010001u) : 0u;
@@ -1436,7 +1441,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     // right here without appending this entry (no_improvement_steps = 0 >= 0), so the index stays
                     if (!PATIENCE || patience > 0) cold[C_BEST_STEP] = e;
                     if (PATIENCE) deadline = (uint32_t)step + patience;
-                    uint8_t* bo = a.out.best_state ? a.out.best_state + chain * (long long)a.state_bytes : nullptr;
+                    uint8_t* bo = a.out.best_state ? a.out.best_state + chain * (long long)state_bytes : nullptr;
                     if (bo) copy_state_out<MODE, G, PATIENCE || REDUCED>(bo, hts, qn, Q, gl);
                 }
             }
@@ -1563,7 +1568,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             if (a.out.near_ties) a.out.near_ties[chain] = cold[C_TIES];
         }
         if (a.out.final_state) {
-            uint8_t* fo = a.out.final_state + chain * (long long)a.state_bytes;
+            uint8_t* fo = a.out.final_state + chain * (long long)state_bytes;
             copy_state_out<MODE, G, PATIENCE || REDUCED>(fo, hts, qn, Q, gl);
         }
     }
@@ -1765,7 +1770,7 @@ int device_simds() {
     return 4 * cus;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -1775,9 +1780,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -1799,6 +1804,7 @@ int launch_sweep_philox(const KArgs& a, hipStream_t s) {
     } else {
         const bool pat = a.patience >= 0 && a.patience <= a.n_steps;  // a patience beyond n_steps can never stop a chain: the plain variants give the same results
         if constexpr (G == 4) {
+            if (!pat && !a.red && a.N == 12) return launch_sweep<MODE, G, false, 3, false, true, 12>(a, s);
             if (!pat && !a.red && (a.N + 3) / 4 == 3) return launch_sweep<MODE, G, false, 3, false, true>(a, s);
         }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true, true>(a, s) : launch_sweep<MODE, G, false, 0, true, true>(a, s);
@@ -1815,7 +1821,7 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             if (a.red && nt == 3) {  // BASELINE config 3's shape with the reduced trace
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
-                return launch_sweep<MODE, G, false, 3, true>(b, s);
+                return a.N == 12 ? launch_sweep<MODE, G, false, 3, true, false, 12>(b, s) : launch_sweep<MODE, G, false, 3, true>(b, s);
             }
             if (!a.red && nt <= 4) {
                 KArgs b = a;
@@ -1823,7 +1829,7 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 switch (nt) {
                 case 1: return launch_sweep<MODE, G, false, 1, false>(b, s);
                 case 2: return launch_sweep<MODE, G, false, 2, false>(b, s);
-                case 3: return launch_sweep<MODE, G, false, 3, false>(b, s);
+                case 3: return a.N == 12 ? launch_sweep<MODE, G, false, 3, false, false, 12>(b, s) : launch_sweep<MODE, G, false, 3, false>(b, s);
                 default: return launch_sweep<MODE, G, false, 4, false>(b, s);
                 }
             }
@@ -1846,9 +1852,11 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             if (pat && !a.red) switch ((a.N + G - 1) / G) {
                 case 1: return launch_sweep<MODE, G, true, 1, false>(a, s);
                 case 2: return launch_sweep<MODE, G, true, 2, false>(a, s);
-                case 3: return launch_sweep<MODE, G, true, 3, false>(a, s);
+                case 3: return a.N == 12 ? launch_sweep<MODE, G, true, 3, false, false, 12>(a, s) : launch_sweep<MODE, G, true, 3, false>(a, s);
                 default: break;
                 }
+            if (!pat && a.N == 12)  // the size of BASELINE config 2: N as a compile-time constant
+                return a.red ? launch_sweep<MODE, G, false, 3, true, false, 12>(a, s) : launch_sweep<MODE, G, false, 3, false, false, 12>(a, s);
             if (!pat) switch ((a.N + G - 1) / G) {
 #define MCQ_NT_CASE(nt) case nt: return a.red ? launch_sweep<MODE, G, false, (nt >= 4 ? 0 : nt), true>(a, s) : launch_sweep<MODE, G, false, nt, false>(a, s)
                 MCQ_NT_CASE(1);  // N = 2..4
