@@ -536,8 +536,10 @@ struct Stream {
     uint32_t* ring;
     uint32_t pos, gen;
     int gi;
-    uint32_t ok_lo, ok_hi;    // bit s: the word in ring slot s passes (w & maskN) <= N-1  (randint(0, N))
-    uint32_t okq_lo, okq_hi;  // HASQ: the same for (w & maskQ) <= Q-1                      (randint(0, Q), full_3d)
+    // Accept flags of the ready words, RELATIVE to the read position: bit b of `ok` says that word pos + b passes (w & maskN) <= N-1
+    // (randint(0, N)); `okq` (HASQ, full_3d) the same for (w & maskQ) <= Q-1 (randint(0, Q)).  Consuming n words shifts them down
+    // by n, a new block is OR-ed in at gen - pos: the low word is the view a batched draw works on, and no bit survives its word.
+    uint64_t ok, okq;
     bool pending;
     uint32_t pa[WPL], pn, px[WPL];
     int gl;
@@ -562,16 +564,17 @@ struct Stream {
         return __builtin_amdgcn_bitop3_b32(odd, tmat, y >> 1, 0x6a) ^ x;           // ((odd & matrix) ^ (y >> 1)) ^ x
     }
 
-    static __device__ __forceinline__ void set_field(uint32_t& lo, uint32_t& hi, int so, uint32_t bits16) {
-        const uint32_t sh = (uint32_t)so & 16u;
-        const uint32_t half = (so & 32) ? hi : lo;
-        const uint32_t upd = (half & ~(0xFFFFu << sh)) | (bits16 << sh);
-        lo = (so & 32) ? lo : upd;
-        hi = (so & 32) ? upd : hi;
+    // the next n words have been used
+    __device__ __forceinline__ void consume(uint32_t n) {
+        pos += n;
+        ok >>= n;
+        if (HASQ) okq >>= n;
     }
-    // accept bits of the 32 ring slots that follow pos
-    static __device__ __forceinline__ uint32_t view(uint32_t lo, uint32_t hi, uint32_t s) {
-        return __builtin_amdgcn_alignbit((s & 32u) ? lo : hi, (s & 32u) ? hi : lo, s & 31u);
+    // flags of the block that lands at word `gen` (16 bits; called before gen advances)
+    __device__ __forceinline__ void add_flags(uint32_t bits16, uint32_t bitsq16) {
+        const uint32_t rel = gen - pos;  // <= 48
+        ok |= (uint64_t)bits16 << rel;
+        if (HASQ) okq |= (uint64_t)bitsq16 << rel;
     }
 
     // MT word `idx` of this chain: uniform base + 32-bit offset, so the address needs no 64-bit vector math
@@ -662,10 +665,9 @@ struct Stream {
 #pragma unroll
             for (int w = 0; w < WPL; w++) bitsq |= ((t[w] & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
             const uint32_t both = group_or<G>(bits | (bitsq << 16));
-            set_field(ok_lo, ok_hi, so, both & 0xffffu);
-            set_field(okq_lo, okq_hi, so, both >> 16);
+            add_flags(both & 0xffffu, both >> 16);
         } else {
-            set_field(ok_lo, ok_hi, so, group_or<G>(bits));
+            add_flags(group_or<G>(bits), 0u);
         }
         gen += 16;
     }
@@ -713,10 +715,9 @@ struct Stream {
         if (i0 == 0) *word(REC_MIRROR) = v[0];
         if (HASQ) {  // both 16-bit masks through one reduction over the group
             const uint32_t both = group_or<G>(bits | (bitsq << 16));
-            set_field(ok_lo, ok_hi, so, both & 0xffffu);
-            set_field(okq_lo, okq_hi, so, both >> 16);
+            add_flags(both & 0xffffu, both >> 16);
         } else {
-            set_field(ok_lo, ok_hi, so, group_or<G>(bits));
+            add_flags(group_or<G>(bits), 0u);
         }
         gen += 16;
         gi = gi + 16 == MT_N ? 0 : gi + 16;
@@ -726,9 +727,10 @@ struct Stream {
     // PHILOX: continue the stream at word rpos (the init kernel consumed the words before it): the 16-word group that holds
     // rpos is generated again and the words in front of rpos are skipped.
     __device__ __forceinline__ void attach_philox(uint32_t key, uint32_t rpos) {
-        pkey = key, pos = rpos, gen = rpos & ~15u, gen_hi = 0, gi = 0;
+        pkey = key, pos = gen = rpos & ~15u, gen_hi = 0, gi = 0, ok = okq = 0;
         generate();
         generate();
+        consume(rpos & 15u);
     }
 
     // continue the stream of a chain record: words [rpos, rge) of the current generation are already
@@ -739,9 +741,9 @@ struct Stream {
         tlow = 0x7fffffffu, tmat = 0x9908b0dfu;
         asm volatile("" : "+s"(tlow), "+s"(tmat));  // opaque scalars, like tc1 / tc2
         okM4 = maskN_ * 0x01010101u, okK4 = (0x80u + mN_) * 0x01010101u;  // maskN, N - 1 <= 31
-        okq_lo = okq_hi = 0;
+        ok = okq = 0;
         pos = (uint32_t)rpos, gen = (uint32_t)rge, gi = rge == MT_N ? 0 : rge;
-        ok_lo = ok_hi = 0, pending = false, pn = 0;
+        pending = false, pn = 0;
         pkey = 0, gen_hi = 0;
 #pragma unroll
         for (int w = 0; w < WPL; w++) pa[w] = px[w] = 0;
@@ -759,8 +761,10 @@ struct Stream {
                     bitsq |= ((x & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
                 }
             }
-            set_field(ok_lo, ok_hi, t0 & (RING - 1), group_or<G>(bits));
-            if (HASQ) set_field(okq_lo, okq_hi, t0 & (RING - 1), group_or<G>(bitsq));
+            // block t0 sits at word t0 - rpos of the view (the first block may start in front of rpos: those flags are not set)
+            const uint64_t f = group_or<G>(bits), fq = HASQ ? group_or<G>(bitsq) : 0u;
+            ok |= t0 >= rpos ? f << (t0 - rpos) : f >> (rpos - t0);
+            if (HASQ) okq |= t0 >= rpos ? fq << (t0 - rpos) : fq >> (rpos - t0);
         }
     }
 };
@@ -1125,7 +1129,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     service = true;  // a second pass means the ring ran dry: finish the block in flight now
                     while (rng.pos != rng.gen && stage_no < LAST) {
                         const uint32_t w = ring[rng.pos & (RING - 1)];
-                        rng.pos++;
+                        rng.consume(1u);
                         const int vN = (int)(w & maskN);
                         const bool okN = (unsigned)vN <= mN;
                         if (MODE == MCQ_MODE_BOARD) {
@@ -1190,22 +1194,18 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // height, and the uniform's two words behind the chosen candidate.  Where the attempt is not valid the
                 // fetched values are simply not used (every address is inside the chain's LDS slice).
                 const uint32_t s = rng.pos & (RING - 1);
-                const uint32_t v1 = rng.view(rng.ok_lo, rng.ok_hi, s);
+                const uint32_t v1 = (uint32_t)rng.ok;
                 const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
-                const uint32_t avail = rng.gen - rng.pos;  // ring slots [pos, pos + avail) hold words; accept bits beyond them are stale
+                const uint32_t avail = rng.gen - rng.pos;  // ring slots [pos, pos + avail) hold words
                 // an empty mask gives position -1 (view_ok is false then): the fetches below read ring[s - 1 ..], still the chain's own LDS
                 const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5);
                 // a fifth accepted word whose two followers are still inside the view and inside the generated words
                 const bool view_ok = (v5 & 0x3fffffffu) != 0 && (uint32_t)(p5 + 2) < avail && !force_slow;
-                // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  Each candidate for new_k is
-                // fetched together with the two words that follow it -- the uniform's words if it becomes new_k -- off one
-                // base address, so nothing has to wait for the old height (one LDS round trip less on the critical path).
+                // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  The uniform's two words follow the
+                // candidate that becomes new_k: they are fetched once that is known (the step is bound by instruction issue, not by
+                // this round trip: fetching them behind all three candidates up front cost 6 selects and 2 LDS instructions more).
                 const uint32_t* rs = ring + s;
-                const uint32_t w1 = rs[p1], w2 = rs[p2];
-                const uint32_t *r3 = rs + p3, *r4 = rs + p4, *r5 = rs + p5;
-                const uint32_t w3 = r3[0], u31 = r3[1], u32 = r3[2];
-                const uint32_t w4 = r4[0], u41 = r4[1], u42 = r4[2];
-                const uint32_t w5 = r5[0], u51 = r5[1], u52 = r5[2];
+                const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3], w4 = rs[p4], w5 = rs[p5];
                 // the stream upkeep runs while those reads are in flight; it appends behind the words of this view
                 if (upkeep_now) upkeep();
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
@@ -1215,18 +1215,18 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 if constexpr (EARLY_PROBES) load_probes();
                 const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
                 pc = use3 ? c3 : use4 ? c4 : c5;
-                const uint32_t kp = (uint32_t)(use3 ? p3 : use4 ? p4 : p5);
-                uw1 = use3 ? u31 : use4 ? u41 : u51, uw2 = use3 ? u32 : use4 ? u42 : u52;
+                const int kp = use3 ? p3 : use4 ? p4 : p5;
+                uw1 = rs[kp + 1], uw2 = rs[kp + 2];  // (an unused attempt reads some words of the chain's ring: kp >= -1)
                 batched = view_ok && pc != old_k;  // three candidates in a row equal to old_k (1/N^3): word by word instead
-                rng.pos += batched ? kp + 3 : 0u;
+                rng.consume(batched ? (uint32_t)kp + 3u : 0u);
             } else {
                 // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
                 // accepted for randint(0, N) after it (the second is used when the first cell is occupied);
                 // the uniform's two words follow the chosen triple.
                 const uint32_t s = rng.pos & (RING - 1);
-                const uint32_t vq = rng.view(rng.okq_lo, rng.okq_hi, s);
+                const uint32_t vq = (uint32_t)rng.okq;
                 const int pq = lowest_bit(vq);  // an empty mask gives -1, like the positions below (view_ok is false then)
-                const uint32_t n1 = rng.view(rng.ok_lo, rng.ok_hi, s) & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
+                const uint32_t n1 = (uint32_t)rng.ok & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
                 const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                 const uint32_t avail = rng.gen - rng.pos;
                 const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3), p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6);
@@ -1234,10 +1234,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
                 const uint32_t* rs = ring + s;
                 const uint32_t wq = rs[pq];
-                const uint32_t w1 = rs[p1], w2 = rs[p2], w4 = rs[p4], w5 = rs[p5];
-                const uint32_t *r3 = rs + p3, *r6 = rs + p6;
-                const uint32_t w3 = r3[0], u31 = r3[1], u32 = r3[2];
-                const uint32_t w6 = r6[0], u61 = r6[1], u62 = r6[2];
+                const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3], w4 = rs[p4], w5 = rs[p5], w6 = rs[p6];
                 if (upkeep_now) upkeep();  // while those reads are in flight
                 const uint32_t vqi = wq & maskQ;
                 qi = (int)(vqi <= mQ ? vqi : 0u);  // an unused attempt must still index inside the queen table
@@ -1248,9 +1245,10 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 asm volatile("" : "+v"(cw1), "+v"(cw2));  // both reads in flight together: one LDS round trip, not one after the other
                 const bool free1 = !((cw1 >> k1) & 1u), free2 = !((cw2 >> k2) & 1u);
                 pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
-                uw1 = free1 ? u31 : u61, uw2 = free1 ? u32 : u62;
+                const int pu = free1 ? p3 : p6;
+                uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
                 batched = view_ok && (free1 || free2);
-                rng.pos += batched ? (uint32_t)(free1 ? p3 : p6) + 3u : 0u;
+                rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
             if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
                 if (!batched) {
@@ -1393,17 +1391,17 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             STAMP(3);  // dE probes + reduce
             // ---- accept iff u < min(1, exp(-beta dE)); the uniform is always drawn -------------------
             // x = -beta dE < 0 iff beta and dE have the same sign (c32 has the sign of -beta); otherwise
-            // the probability is 1 (also for a NaN beta, like min(1.0, nan) in the reference).
-            // sgn (wave-uniform, from the bits of c32): +1 for beta > 0, -1 for beta < 0, 0 for a zero or NaN beta
-            const uint32_t cbits = __float_as_uint(c32), cmag = cbits & 0x7fffffffu;
-            const int sgn = (cmag == 0u || cmag > 0x7f800000u) ? 0 : ((cbits >> 31) ? 1 : -1);
-            const bool xneg = __mul24(dE, sgn) > 0;
+            // the probability is 1 (also for a NaN beta, like min(1.0, nan) in the reference).  The sign comes from the float32
+            // product dE * c32: no rounding can change it (|dE| >= 1 or the product is an exact zero), and a c32 that underflowed to
+            // zero stands for a |x| far below 2^-54, where exp(x) rounds to 1.0 in float64 as well.
+            const float fdE = (float)dE;
+            const bool xneg = fdE * c32 < 0.0f;  // exact in sign; false for a zero or NaN c32 (and for inf * 0), like !(x < 0.0) in float64
             // u * 2^27 lies in [a27, a27 + 1), a27 = the top 27 bits of u; e27 = exp(x) * 2^27 within 3e-5 relative.
             // d = a27 + 1/2 - e27 and the half-width w = e27 * 2^-10 + 1/2: d < -w accepts for sure (a27 + 1 < e27 (1 - 2^-10)),
             // d > w rejects for sure (a27 > e27 (1 + 2^-10)), in between the float64 path decides.  Both tests end in one
             // compare whose operand carries the x < 0 condition, so each result is a lane mask straight from the compare.
             const float fa = (float)(uw1 >> 5);
-            const float e27 = __builtin_amdgcn_exp2f(fmaf((float)dE, c32, 27.0f));
+            const float e27 = __builtin_amdgcn_exp2f(fmaf(fdE, c32, 27.0f));
             const float d = (fa + 0.5f) - e27;
             const float w = exact_only ? 3.0e38f : fmaf(e27, 0.0009765625f, 0.5f);
             bool exact = __builtin_fabsf(d) <= (xneg ? w : -1.0f);
@@ -1417,7 +1415,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             }
 
             STAMP(4);  // accept test
-            accw |= acc ? 1u << (step & 31) : 0u;
+            accw = __builtin_amdgcn_alignbit(acc ? 1u : 0u, accw, 1);  // the flag enters at bit 31: after 32 steps the first of them sits in bit 0
             if (MODE == MCQ_MODE_BOARD) {
                 hts[cell] = (uint8_t)(acc ? pc : old_k);  // every lane of the group writes the same byte; a rejected move rewrites the old height
             } else if (acc) {
@@ -1449,7 +1447,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             // the common tail of a step: append the entry, flush full blocks, pace
             auto append_entry = [&]() {
                 stage[e & 15] = (uint32_t)E | (reduced ? (acc ? 0xC0000000u : 0x40000000u) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
-                if ((e & 15) == 15 && trace) {  // one aligned 64-byte segment per chain
+                if ((e & 15) == 15) if (trace) {  // one aligned 64-byte segment per chain
 #ifdef MCQ_EXP_NT_TRACE
                     if constexpr (WPL == 4) {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1497,7 +1495,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                             for (int w = 0; w < WPL; w++)
                                 if (gl * WPL + w <= (step & 15)) hist_at(step & ~15)[w] = (int)stage[gl * WPL + w];
                         cold[C_N_ACC] += __popc(accw);
-                        if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
+                        if (have_bits && gl == 0) *bits_at(step >> 5) = accw >> (31 - (step & 31));  // (step & 31) + 1 flags so far
                     } else {
                         append_entry();
                     }
@@ -1554,7 +1552,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             for (int w = 0; w < WPL; w++)
                 if (gl * WPL + w <= (n_steps & 15)) hist_at(n_steps & ~15)[w] = (int)stage[gl * WPL + w];
         if ((n_steps & 31) != 0) cold[C_N_ACC] += __popc(accw);
-        if (have_bits && gl == 0 && (n_steps & 31) != 0) *bits_at(n_steps >> 5) = accw;
+        if (have_bits && gl == 0 && (n_steps & 31) != 0) *bits_at(n_steps >> 5) = accw >> (32 - (n_steps & 31));  // n_steps & 31 flags in the last word
     }
     if (chain < a.n_chains) {
         if (gl == 0) {
