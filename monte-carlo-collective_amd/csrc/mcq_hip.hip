@@ -986,7 +986,9 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
+    const uint32_t batch_mask = force_slow ? 0u : 0xffffffffu;  // wave-uniform
     const bool trace = a.out.energy_hist != nullptr;
+    const int flush_at = trace ? 15 : 99;
     // trace rows: wave-uniform address of the wavefront's first row (scalar registers) + a 32-bit byte offset per lane, so that no
     // 64-bit pointer is held in vector registers (16 rows of hist_stride < 2^24 entries span < 2^30 bytes: checked by the host side)
     char* const hist_base = trace ? (char*)(a.out.energy_hist + (long long)blockIdx.x * CPW * a.hist_stride) : nullptr;
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
         STAMP(0);  // loop overhead + previous step's tail
         const int step = ALL ? vstep : __builtin_amdgcn_readfirstlane(vstep);
         vstep = step + 1;
-        const float c32 = c32_tab[step];  // exp(-beta dE) = exp2(dE * c32)
+        const float c32 = c32_tab[(uint32_t)step];  // exp(-beta dE) = exp2(dE * c32)  (unsigned index: a scalar load with a 32-bit offset register)
         // what closes a step for the whole wavefront (stopped and idle lanes included): REDUCED adds every 16th block of entries
         // to the accumulators.  SOME_INACTIVE = false: every lane is a live chain (the ALL form's common path).
         auto end_of_step = [&](auto some_inactive) __attribute__((always_inline)) {
@@ -1197,10 +1199,12 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 const uint32_t v1 = (uint32_t)rng.ok;
                 const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
                 const uint32_t avail = rng.gen - rng.pos;  // ring slots [pos, pos + avail) hold words
-                // an empty mask gives position -1 (view_ok is false then): the fetches below read ring[s - 1 ..], still the chain's own LDS
-                const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5);
-                // a fifth accepted word whose two followers are still inside the view and inside the generated words
-                const bool view_ok = (v5 & 0x3fffffffu) != 0 && (uint32_t)(p5 + 2) < avail && !force_slow;
+                // an empty mask gives position -1 (the attempt is not used then): the fetches below read ring[s - 1 ..], still the chain's own LDS
+                // the fifth accepted word must leave its two followers inside the view: positions 0..29 (none there: p5 = -1)
+                const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5 & 0x3fffffffu);
+                // ... and inside the generated words: p5 + 2 < avail (avail >= 5 when there is a fifth word).  As ONE unsigned compare,
+                // p5 < draw_limit: no fifth word (0xffffffff) fails it, and so does everything under MCQ_FLAG_SEQUENTIAL_DRAWS (limit 0)
+                const uint32_t draw_limit = (avail - 2u) & batch_mask;
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  The uniform's two words follow the
                 // candidate that becomes new_k: they are fetched once that is known (the step is bound by instruction issue, not by
                 // this round trip: fetching them behind all three candidates up front cost 6 selects and 2 LDS instructions more).
@@ -1217,7 +1221,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 pc = use3 ? c3 : use4 ? c4 : c5;
                 const int kp = use3 ? p3 : use4 ? p4 : p5;
                 uw1 = rs[kp + 1], uw2 = rs[kp + 2];  // (an unused attempt reads some words of the chain's ring: kp >= -1)
-                batched = view_ok && pc != old_k;  // three candidates in a row equal to old_k (1/N^3): word by word instead
+                // three candidates in a row equal to old_k (1/N^3): word by word instead
+                batched = (pc != old_k ? (uint32_t)p5 : 0xffffffffu) < draw_limit;
                 rng.consume(batched ? (uint32_t)kp + 3u : 0u);
             } else {
                 // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
@@ -1225,12 +1230,12 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // the uniform's two words follow the chosen triple.
                 const uint32_t s = rng.pos & (RING - 1);
                 const uint32_t vq = (uint32_t)rng.okq;
-                const int pq = lowest_bit(vq);  // an empty mask gives -1, like the positions below (view_ok is false then)
+                const int pq = lowest_bit(vq);  // an empty mask gives -1 (and leaves n1 empty), like the positions below
                 const uint32_t n1 = (uint32_t)rng.ok & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
                 const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                 const uint32_t avail = rng.gen - rng.pos;
-                const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3), p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6);
-                const bool view_ok = vq != 0 && (n6 & 0x3fffffffu) != 0 && (uint32_t)(p6 + 2) < avail && !force_slow;
+                const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3), p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6 & 0x3fffffffu);
+                const uint32_t draw_limit = (avail - 2u) & batch_mask;  // p6 + 2 < avail as p6 < draw_limit (see the board branch)
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
                 const uint32_t* rs = ring + s;
                 const uint32_t wq = rs[pq];
@@ -1247,7 +1252,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
                 const int pu = free1 ? p3 : p6;
                 uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
-                batched = view_ok && (free1 || free2);
+                batched = (free1 || free2 ? (uint32_t)p6 : 0xffffffffu) < draw_limit;
                 rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
             if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
@@ -1405,17 +1410,17 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             const float d = (fa + 0.5f) - e27;
             const float w = exact_only ? 3.0e38f : fmaf(e27, 0.0009765625f, 0.5f);
             bool exact = __builtin_fabsf(d) <= (xneg ? w : -1.0f);
-            bool acc = (xneg ? d : -1.0f) < 0.0f;
+            uint32_t acc = (xneg ? d : -1.0f) < 0.0f ? 1u : 0u;  // 0 / 1 in a vector register: the rare branch below may rewrite it
             if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
                 if (exact) {
                     const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
-                    acc = (r & 1) != 0;
+                    acc = (uint32_t)r & 1u;
                     if (r >> 1) cold[C_TIES] += 1;
                 }
             }
 
             STAMP(4);  // accept test
-            accw = __builtin_amdgcn_alignbit(acc ? 1u : 0u, accw, 1);  // the flag enters at bit 31: after 32 steps the first of them sits in bit 0
+            accw = __builtin_amdgcn_alignbit(acc, accw, 1);  // the flag enters at bit 31: after 32 steps the first of them sits in bit 0
             if (MODE == MCQ_MODE_BOARD) {
                 hts[cell] = (uint8_t)(acc ? pc : old_k);  // every lane of the group writes the same byte; a rejected move rewrites the old height
             } else if (acc) {
@@ -1429,7 +1434,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 colw[__mul24(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | (1u << pc));
                 qn[qi] = (uint16_t)newp;
             }
-            E += acc ? dE : 0;
+            E += __mul24((int)acc, dE);  // E += acc ? dE : 0  (|dE| <= 8 N)
             const bool improved = E < best;  // only an accepted move can get below the best so far (E >= best otherwise)
             best = min(best, E);
             const int e = step + 1;
@@ -1446,8 +1451,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
 
             // the common tail of a step: append the entry, flush full blocks, pace
             auto append_entry = [&]() {
-                stage[e & 15] = (uint32_t)E | (reduced ? (acc ? 0xC0000000u : 0x40000000u) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
-                if ((e & 15) == 15) if (trace) {  // one aligned 64-byte segment per chain
+                stage[e & 15] = (uint32_t)E | (reduced ? 0x40000000u | (acc << 31) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
+                if ((e & 15) == flush_at) {  // one aligned 64-byte segment per chain (flush_at = 15, or out of reach without a trace)
 #ifdef MCQ_EXP_NT_TRACE
                     if constexpr (WPL == 4) {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1459,17 +1464,17 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     else if constexpr (WPL == 2) *(uint2*)hist_at(e - 15) = *(const uint2*)(stage + gl * 2);
                     else *hist_at(e - 15) = (int)stage[gl];
                 }
-                if ((step & 31) == 31) {
+                if ((e & 31) == 0) {
                     cold[C_N_ACC] += __popc(accw);  // accepted moves are counted from the bit words
-                    if (have_bits && gl == 0) *bits_at(step >> 5) = accw;
+                    if (have_bits && gl == 0) *bits_at((e >> 5) - 1) = accw;
                     accw = 0;
 #ifndef MCQ_PACE_MASK
 #define MCQ_PACE_MASK 63
 #endif
-                    if ((step & MCQ_PACE_MASK) == MCQ_PACE_MASK && a.pace) {
+                    if ((e & MCQ_PACE_MASK) == 0 && a.pace) {
                         // Pacing: publish this wavefront's progress, read the row of its SIMD, and take a priority that grows with
                         // the number of co-resident wavefronts that are further along (ties fall to the arbiter's age order).
-                        const uint32_t mine = (uint32_t)step + 1u;
+                        const uint32_t mine = (uint32_t)e;
                         if (lane == 0) __hip_atomic_store(pace_row + wave_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const uint32_t other = lane < 16 ? __hip_atomic_load(pace_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                         set_priority(min(3, (int)__popcll(__ballot(other > mine))));
