@@ -303,13 +303,32 @@ __device__ __forceinline__ uint32_t abs_diff(int a, int b) {
     return d;
 }
 
+// a * b of two values below 2^24 as the full-rate 24-bit multiply (the compiler turns __mul24 of values it can bound into a plain
+// 32-bit multiply, which runs at a quarter of the rate)
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// x * N for a coordinate x; with a compile-time N (NC != 0) through the 24-bit multiply with an inline constant
+template <int NC>
+__device__ __forceinline__ int times_N(int x, int N) {
+    if constexpr (NC != 0) {
+        uint32_t d;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(x), "n"(NC));
+        return (int)d;
+    } else {
+        return __mul24(x, N);
+    }
+}
+
 // two distinct cells attack each other iff they share one of the 13 lines: every non-zero
 // coordinate offset has the same magnitude.
-// (branch-free: x is 0 or m iff x (m - x) == 0; coordinates are below 32, so the products fit 24-bit multiplies)
-__device__ __forceinline__ bool on_a_line(int di, int dj, int dk) {
-    const int a = di < 0 ? -di : di, b = dj < 0 ? -dj : dj, c = dk < 0 ? -dk : dk;
-    const int m = max(a, max(b, c));
-    return (__mul24(a, m - a) | __mul24(b, m - b) | __mul24(c, m - c)) == 0;
+// (branch-free: x is 0 or m iff x (m - x) == 0; a, b, c = the magnitudes of the three offsets, below 32)
+__device__ __forceinline__ bool on_a_line(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t m = max(a, max(b, c));
+    return (mul_u24(a, m - a) | mul_u24(b, m - b) | mul_u24(c, m - c)) == 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -986,9 +1005,11 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
-    const uint32_t batch_mask = force_slow ? 0u : 0xffffffffu;  // wave-uniform
+    uint32_t batch_mask = force_slow ? 0u : 0xffffffffu;  // wave-uniform
+    asm volatile("" : "+s"(batch_mask));
     const bool trace = a.out.energy_hist != nullptr;
-    const int flush_at = trace ? 15 : 99;
+    int flush_at = trace ? 15 : 99;
+    asm volatile("" : "+s"(flush_at));  // an opaque scalar: one compare per step, whatever the compiler could derive from the 99
     // trace rows: wave-uniform address of the wavefront's first row (scalar registers) + a 32-bit byte offset per lane, so that no
     // 64-bit pointer is held in vector registers (16 rows of hist_stride < 2^24 entries span < 2^30 bytes: checked by the host side)
     char* const hist_base = trace ? (char*)(a.out.energy_hist + (long long)blockIdx.x * CPW * a.hist_stride) : nullptr;
@@ -1222,7 +1243,9 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 const int kp = use3 ? p3 : use4 ? p4 : p5;
                 uw1 = rs[kp + 1], uw2 = rs[kp + 2];  // (an unused attempt reads some words of the chain's ring: kp >= -1)
                 // three candidates in a row equal to old_k (1/N^3): word by word instead
-                batched = (pc != old_k ? (uint32_t)p5 : 0xffffffffu) < draw_limit;
+                uint32_t fifth = pc != old_k ? (uint32_t)p5 : 0xffffffffu;
+                asm volatile("" : "+v"(fifth));  // (keeps it one compare: the compiler would take the select apart into mask logic again)
+                batched = fifth < draw_limit;
                 rng.consume(batched ? (uint32_t)kp + 3u : 0u);
             } else {
                 // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
@@ -1252,7 +1275,9 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
                 const int pu = free1 ? p3 : p6;
                 uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
-                batched = (free1 || free2 ? (uint32_t)p6 : 0xffffffffu) < draw_limit;
+                uint32_t sixth = free1 || free2 ? (uint32_t)p6 : 0xffffffffu;
+                asm volatile("" : "+v"(sixth));  // (keeps it one compare, as in the board branch)
+                batched = sixth < draw_limit;
                 rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
             if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
@@ -1358,7 +1383,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     const int ci = oldside ? oi : ni, cj = oldside ? oj : nj;
                     const uint32_t B = oldside ? Bo : Bn, BB = B | (B << 16);
                     const uint32_t shd = (uint32_t)(cj - ci + 16), sha = (uint32_t)(ci + cj);
-                    const colw_t* crow = colw + __mul24(ci, N);
+                    const colw_t* crow = colw + times_N<NC>(ci, N);
                     uint32_t cnt = 0;
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
@@ -1387,9 +1412,9 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // side, i.e. +4.  Own columns (the k-axis lines): popc(W) minus the moving queen on the old side.  On the
                 // new side the moving queen still sits at the old cell; if that lies on a line through the new cell it was
                 // counted and is removed.
-                cw_new = colw[__mul24(ni, N) + nj], cw_old = colw[__mul24(oi, N) + oj];  // kept: an accepted move rewrites them without reading again
+                cw_new = colw[times_N<NC>(ni, N) + nj], cw_old = colw[times_N<NC>(oi, N) + oj];  // kept: an accepted move rewrites them without reading again
                 const int own_new = __popc(cw_new), own_old = __popc(cw_old) - 1;
-                const int moving = on_a_line(oi - ni, oj - nj, ok_ - nk) ? 1 : 0;
+                const int moving = on_a_line(abs_diff(oi, ni), abs_diff(oj, nj), abs_diff(ok_, nk)) ? 1 : 0;
                 dE = group_sum<G>(part) + 4 + own_new - own_old - moving;
             }
 
@@ -1430,8 +1455,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 const uint32_t op_i = oldp & 31, op_j = (oldp >> 5) & 31;
                 const uint32_t cleared = cw_old & ~(1u << ((oldp >> 10) & 31));
                 const bool same_column = op_i == (uint32_t)pa && op_j == (uint32_t)pb;
-                colw[__mul24((int)op_i, N) + (int)op_j] = (colw_t)cleared;
-                colw[__mul24(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | (1u << pc));
+                colw[times_N<NC>((int)op_i, N) + (int)op_j] = (colw_t)cleared;
+                colw[times_N<NC>(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | (1u << pc));
                 qn[qi] = (uint16_t)newp;
             }
             E += __mul24((int)acc, dE);  // E += acc ? dE : 0  (|dE| <= 8 N)
