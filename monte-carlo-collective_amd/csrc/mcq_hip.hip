@@ -929,7 +929,8 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // use the registers of a 2-per-SIMD kernel)
 // NC: the board size as a compile-time constant (0: taken from the arguments).  The probe addresses of the later passes are the
 // first pass's plus multiples of N: with N known they become immediate offsets of the LDS reads instead of an addition each
-// (12 vector instructions of ~208 per step on the headline problem); instantiated for N = 12, the size of BASELINE configs 2 and 3.
+// (12 vector instructions of ~208 per step on the headline problem); instantiated for N = 12, the size of BASELINE configs 2 and 3,
+// and for config 5's N = 24 (8 lanes, reduced trace).
 template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0>
 __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : 4) void mcq_sweep_kernel(KArgs a) {
     WAVE_T0;
@@ -1004,6 +1005,10 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                                       : nullptr;
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
+    // half-width of the float32 bracket around exp(x) 2^27 as w = e27 * w_scale + w_bias; MCQ_FLAG_EXACT_EXP makes it cover everything
+    uint32_t w_scale_bits = exact_only ? 0u : 0x3a800000u /* 2^-10 */, w_bias_bits = exact_only ? 0x7f61b1e6u /* 3.0e38 */ : 0x3f000000u /* 0.5 */;
+    asm volatile("" : "+s"(w_scale_bits), "+s"(w_bias_bits));  // two scalars, no select per step
+    const float w_scale = __uint_as_float(w_scale_bits), w_bias = __uint_as_float(w_bias_bits);
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
     uint32_t batch_mask = force_slow ? 0u : 0xffffffffu;  // wave-uniform
     asm volatile("" : "+s"(batch_mask));
@@ -1433,7 +1438,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             const float fa = (float)(uw1 >> 5);
             const float e27 = __builtin_amdgcn_exp2f(fmaf(fdE, c32, 27.0f));
             const float d = (fa + 0.5f) - e27;
-            const float w = exact_only ? 3.0e38f : fmaf(e27, 0.0009765625f, 0.5f);
+            const float w = fmaf(e27, w_scale, w_bias);  // (x < 0 here whenever w is used: e27 <= 2^27)
             bool exact = __builtin_fabsf(d) <= (xneg ? w : -1.0f);
             uint32_t acc = (xneg ? d : -1.0f) < 0.0f ? 1u : 0u;  // 0 / 1 in a vector register: the rare branch below may rewrite it
             if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
@@ -1898,7 +1903,8 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 }
         }
         if constexpr (G == 8) {  // larger boards run 8 lanes per chain by default: 3 or 4 straight-line probe passes
-            if (!pat && a.red && a.N > 16 && a.N <= 24) return launch_sweep<MODE, G, false, 3, true>(a, s);  // the beta-pair driver's shape (N = 24, reduced trace)
+            if (!pat && a.red && a.N == 24) return launch_sweep<MODE, G, false, 3, true, false, 24>(a, s);  // BASELINE config 5: the beta-pair driver's shape (N = 24, reduced trace)
+            if (!pat && a.red && a.N > 16 && a.N <= 24) return launch_sweep<MODE, G, false, 3, true>(a, s);
             if (!pat && a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, false, 2, true>(a, s);
             if (!pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
             if (!pat && !a.red && a.N > 8) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
