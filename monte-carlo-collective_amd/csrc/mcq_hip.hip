@@ -18,15 +18,15 @@
 //   * MT19937: the 624 raw state words of a chain stay in its record in global memory and are
 //     regenerated in place in blocks of 16 (16/G per lane), requested one or more steps before
 //     they are needed; the block is twisted, tempered and appended to a 64-slot ring of ready
-//     words in LDS (its first 32 slots mirrored behind it), together with one bit per slot that
-//     says whether the word passes the masked-rejection test of randint(0, N).  This upkeep is
-//     demand-driven and runs for all chains of the wavefront together, so the lanes stay converged.
+//     words in LDS (its first 32 slots mirrored behind it), together with one flag per word that
+//     says whether it passes the masked-rejection test of randint(0, N); the flags live in a
+//     64-bit register pair indexed from the read position.  This upkeep is demand-driven and
+//     runs for all chains of the wavefront together, so the lanes stay converged.
 //   * proposal (board): the positions of the next five accepted words come from bit tricks on the
-//     32-slot view of the accept bits (no rejection loop, no divergence); i, j and three
-//     candidates for new_k are fetched in one batch, each candidate with the two words behind it,
-//     which are the uniform's if that candidate is taken.  Anything unusual (ring nearly empty,
-//     all candidates equal to old_k, rejection run longer than the view) takes a sequential
-//     fallback that draws word by word -- same stream, same results.
+//     low word of the flags (no rejection loop, no divergence); i, j and three candidates for
+//     new_k are fetched in one batch, the uniform's two words behind the candidate that is taken.
+//     Anything unusual (ring nearly empty, all candidates equal to old_k, rejection run longer
+//     than the view) takes a sequential fallback that draws word by word -- same stream, same results.
 //   * dE (board): only columns on the row, column and two diagonals of (i,j) in the ij-plane
 //     can attack cell (i,j,k), at most 4N of them; a column at in-plane distance d with height
 //     h attacks iff |h-k| is 0 or d, i.e. iff bit h of (B | B<<d | B>>d), B = 1<<k, is set.
@@ -43,6 +43,9 @@
 //     segment; accept bits are flushed as 32-bit words.
 //   * pacing: the wavefronts of a SIMD compare their progress through a small table and set
 //     s_setprio so that they finish together (see set_priority below).
+//   * the step is bound by instruction issue (four wavefronts per SIMD): the hot
+//     loop is written for few instructions per step, and the sizes of BASELINE's configs (N = 12,
+//     N = 24) have instantiations with N as a compile-time constant.
 //
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include <hip/hip_runtime.h>
@@ -540,8 +543,8 @@ __device__ __forceinline__ uint32_t group_or(uint32_t u) {
 // words per lane: the block's inputs are loaded (`issue`) one or more Metropolis steps before they are
 // consumed (`complete`), so the memory latency is covered by the steps in between; `complete`
 // twists, writes the new raw words back in place, tempers them and appends them to a 64-slot ring
-// of ready words in LDS together with one accept bit per slot ((w & maskN) <= N-1, the masked
-// rejection test of randint(0, N)).
+// of ready words in LDS and records one accept flag per word ((w & maskN) <= N-1, the masked
+// rejection test of randint(0, N)) in the register pair `ok`.
 //   pos, gen   absolute counters of consumed / generated words; ring slot = counter & 63
 //   gi         MT index of the next block to generate (multiple of 16, wraps at 624)
 //
@@ -1830,7 +1833,7 @@ int launch_sweep_philox(const KArgs& a, hipStream_t s) {
             if (!a.red && (a.N + 3) / 4 == 3) {
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
-                return launch_sweep<MODE, G, false, 3, false, true>(b, s);
+                return a.N == 12 ? launch_sweep<MODE, G, false, 3, false, true, 12>(b, s) : launch_sweep<MODE, G, false, 3, false, true>(b, s);
             }
         }
         return a.red ? launch_sweep<MODE, G, false, 0, true, true>(a, s) : launch_sweep<MODE, G, false, 0, false, true>(a, s);
