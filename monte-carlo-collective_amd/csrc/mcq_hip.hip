@@ -1256,36 +1256,47 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 batched = fifth < draw_limit;
                 rng.consume(batched ? (uint32_t)kp + 3u : 0u);
             } else {
-                // q = first word accepted for randint(0, Q); then two candidate (i, j, k) triples from the words
-                // accepted for randint(0, N) after it (the second is used when the first cell is occupied);
-                // the uniform's two words follow the chosen triple.
+                // q = first word accepted for randint(0, Q); then a candidate (i, j, k) triple from the words accepted for
+                // randint(0, N) after it, and a second triple when the first cell is occupied; the uniform's two words follow the
+                // chosen triple.
                 const uint32_t s = rng.pos & (RING - 1);
                 const uint32_t vq = (uint32_t)rng.okq;
                 const int pq = lowest_bit(vq);  // an empty mask gives -1 (and leaves n1 empty), like the positions below
                 const uint32_t n1 = (uint32_t)rng.ok & (0xFFFFFFFEu << ((uint32_t)pq & 31u));
-                const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1), n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
+                const uint32_t n2 = n1 & (n1 - 1), n3 = n2 & (n2 - 1);
                 const uint32_t avail = rng.gen - rng.pos;
-                const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3), p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6 & 0x3fffffffu);
-                const uint32_t draw_limit = (avail - 2u) & batch_mask;  // p6 + 2 < avail as p6 < draw_limit (see the board branch)
+                // the third word must leave its two followers (the uniform's) inside the view: positions 0..29 (none there: p3 = -1)
+                const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3 & 0x3fffffffu);
+                const uint32_t draw_limit = (avail - 2u) & batch_mask;  // p + 2 < avail as p < draw_limit (see the board branch)
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
                 const uint32_t* rs = ring + s;
                 const uint32_t wq = rs[pq];
-                const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3], w4 = rs[p4], w5 = rs[p5], w6 = rs[p6];
+                const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3];
                 if (upkeep_now) upkeep();  // while those reads are in flight
                 const uint32_t vqi = wq & maskQ;
                 qi = (int)(vqi <= mQ ? vqi : 0u);  // an unused attempt must still index inside the queen table
                 oldp = qn[qi];
-                const int i1 = (int)(w1 & maskN), j1 = (int)(w2 & maskN), k1 = (int)(w3 & maskN) & 31;
-                const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
-                uint32_t cw1 = colw[__mul24(i1, N) + j1], cw2 = colw[__mul24(i2, N) + j2];  // word index < 2^10: inside the workgroup's LDS
-                asm volatile("" : "+v"(cw1), "+v"(cw2));  // both reads in flight together: one LDS round trip, not one after the other
-                const bool free1 = !((cw1 >> k1) & 1u), free2 = !((cw2 >> k2) & 1u);
-                pa = free1 ? i1 : i2, pb = free1 ? j1 : j2, pc = free1 ? k1 : k2;
-                const int pu = free1 ? p3 : p6;
+                pa = (int)(w1 & maskN), pb = (int)(w2 & maskN), pc = (int)(w3 & maskN) & 31;
+                const uint32_t cw1 = colw[__mul24(pa, N) + pb];  // word index < 2^10: inside the workgroup's LDS
+                const bool free1 = !((cw1 >> pc) & 1u);
+                int pu = p3;
+                uint32_t third = free1 ? (uint32_t)p3 : 0xffffffffu;
+                asm volatile("" : "+v"(third));  // (keeps it one compare, as in the board branch)
+                batched = third < draw_limit;
+                // The cell of the first triple is taken with probability Q / N^3 (1/12 at N = 12): only then -- for some chain of the
+                // wavefront, so in every second step of 8 chains -- is the second triple looked at (it was fetched up front before:
+                // ~30 instructions per step; the step is bound by instruction issue, not by this extra round trip).
+                if (wave_any(!batched)) {
+                    const uint32_t n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
+                    const int p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6 & 0x3fffffffu);
+                    const uint32_t w4 = rs[p4], w5 = rs[p5], w6 = rs[p6];
+                    const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
+                    const uint32_t cw2 = colw[__mul24(i2, N) + j2];
+                    const bool second = !batched && !free1 && !((cw2 >> k2) & 1u) && (uint32_t)p6 < draw_limit;
+                    pa = second ? i2 : pa, pb = second ? j2 : pb, pc = second ? k2 : pc, pu = second ? p6 : pu;
+                    batched = batched || second;
+                }
                 uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
-                uint32_t sixth = free1 || free2 ? (uint32_t)p6 : 0xffffffffu;
-                asm volatile("" : "+v"(sixth));  // (keeps it one compare, as in the board branch)
-                batched = sixth < draw_limit;
                 rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
             if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
