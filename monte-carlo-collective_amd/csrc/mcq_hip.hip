@@ -306,14 +306,6 @@ __device__ __forceinline__ uint32_t abs_diff(int a, int b) {
     return d;
 }
 
-// a * b of two values below 2^24 as the full-rate 24-bit multiply (the compiler turns __mul24 of values it can bound into a plain
-// 32-bit multiply, which runs at a quarter of the rate)
-__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
-    uint32_t d;
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
 // x * N for a coordinate x; with a compile-time N (NC != 0) through the 24-bit multiply with an inline constant
 template <int NC>
 __device__ __forceinline__ int times_N(int x, int N) {
@@ -326,12 +318,20 @@ __device__ __forceinline__ int times_N(int x, int N) {
     }
 }
 
-// two distinct cells attack each other iff they share one of the 13 lines: every non-zero
-// coordinate offset has the same magnitude.
-// (branch-free: x is 0 or m iff x (m - x) == 0; a, b, c = the magnitudes of the three offsets, below 32)
-__device__ __forceinline__ bool on_a_line(uint32_t a, uint32_t b, uint32_t c) {
-    const uint32_t m = max(a, max(b, c));
-    return (mul_u24(a, m - a) | mul_u24(b, m - b) | mul_u24(c, m - c)) == 0;
+// |a - b| - 1 (wrapping: 0xffffffff for a == b) in one instruction
+__device__ __forceinline__ uint32_t abs_diff_minus_1(int a, int b) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, -1" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// Two distinct cells attack each other iff they share one of the 13 lines: every non-zero coordinate offset has the same
+// magnitude.  With a, b, c = the three magnitudes minus one (a zero offset becomes 0xffffffff = -1): the largest magnitude is the
+// SIGNED maximum, the smallest non-zero one the UNSIGNED minimum, and the cells share a line iff the two are equal.
+__device__ __forceinline__ bool on_a_line_m1(uint32_t a, uint32_t b, uint32_t c) {
+    const int hi = max((int)a, max((int)b, (int)c));
+    const uint32_t lo = min(a, min(b, c));
+    return (uint32_t)hi == lo;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // counted and is removed.
                 cw_new = colw[times_N<NC>(ni, N) + nj], cw_old = colw[times_N<NC>(oi, N) + oj];  // kept: an accepted move rewrites them without reading again
                 const int own_new = __popc(cw_new), own_old = __popc(cw_old) - 1;
-                const int moving = on_a_line(abs_diff(oi, ni), abs_diff(oj, nj), abs_diff(ok_, nk)) ? 1 : 0;
+                const int moving = on_a_line_m1(abs_diff_minus_1(oi, ni), abs_diff_minus_1(oj, nj), abs_diff_minus_1(ok_, nk)) ? 1 : 0;
                 dE = group_sum<G>(part) + 4 + own_new - own_old - moving;
             }
 
