@@ -157,7 +157,8 @@ const char* mcq_last_error(void);
 int mcq_device_count(void);
 
 /* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 12 and 8 beyond, full_3d 8
- * (mcq_default_lanes: the value for small boards) */
+ * (mcq_default_lanes: the value for small boards).  A board launch too small to give every SIMD a wavefront at 4 lanes per
+ * chain (n_chains / 16 < 4 x compute units) runs at 8.  The lane count never changes a result. */
 int32_t mcq_default_lanes(int32_t mode);
 int32_t mcq_default_lanes_n(int32_t mode, int32_t N);
 

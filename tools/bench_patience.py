@@ -11,6 +11,6 @@ for pat in (None, 20000, 2000):
     p = abi.make_params(12, 20000, "random", sp, 65536, mcmc_type="board", early_stop_patience=pat, trace=True)
     run = mcq_amd._lib.DeviceRun(p, abi.seeds_for(42, 65536), trace=True, states=False)
     run.launch(); torch.cuda.synchronize()
-    i, s = run.launch_timed()
-    print("patience", pat, "sweep ms %.2f" % s, "executed", int(run.t["steps_executed"].sum().item()))
+    ms = [run.launch_timed()[1] for _ in range(5)]  # (single launches scatter by ~1 %)
+    print("patience", pat, "sweep ms min %.2f mean %.2f of 5" % (min(ms), sum(ms) / len(ms)), "executed", int(run.t["steps_executed"].sum().item()))
     del run; torch.cuda.empty_cache()
