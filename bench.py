@@ -206,12 +206,16 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc["bytes_per_launch"] if pmc else None,
             "kernel": "mcq_sweep_kernel",
-            "note": "algorithmic bytes = 4.125 B/move (int32 trace entry + accept bit); the sweep is issue/latency bound, see DESIGN.md",
+            "note": "algorithmic bytes = 4.125 B/move (int32 trace entry + accept bit); on the chip the sweep is bound by instruction issue, "
+                    "and the MT19937 state stream it carries moves ~25x those bytes (traffic_frac): DESIGN.md 4.3",
         },
     }
     if pmc:
         if algo_bytes:
             line["roofline"]["traffic_ratio"] = pmc["bytes_per_launch"] / algo_bytes  # measured fabric bytes over algorithmic bytes
+        # the same kernel against the same peak on the bytes it really moves (PMC count per launch over the live kernel time)
+        line["roofline"]["traffic_rate"] = pmc["bytes_per_launch"] / (sweep_avg_ms * 1e-3) / 1e9
+        line["roofline"]["traffic_frac"] = line["roofline"]["traffic_rate"] / HBM_PEAK_GBS
         line["roofline"]["traffic_source"] = {k: pmc[k] for k in ("kernel_sha256", "commit", "read_bytes", "write_bytes", "l2_hit_rate") if k in pmc}
         if pmc.get("valu_insts_per_launch"):
             # the on-chip view of the same kernel: wave64 VALU instructions (PMC count of this workload) over the live kernel
