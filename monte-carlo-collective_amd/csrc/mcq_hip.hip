@@ -603,7 +603,7 @@ struct Stream {
     __device__ __forceinline__ uint32_t* word(int idx) const { return (uint32_t*)(wbase + (coff + 4u * (uint32_t)idx)); }
     // Timing experiments (tools/exp_build.sh; never defined in the shipped library, results are wrong with any of them):
     // MCQ_EXP_HOT_LOADS / MCQ_EXP_HOT_STORES fold the block's reads / writes onto the first 64 words of the record (cache-resident),
-    // MCQ_EXP_NO_STORE drops the write-back, MCQ_EXP_NT_* mark accesses non-temporal.
+    // MCQ_EXP_NO_STORE drops the write-back, MCQ_EXP_NT_STORE / MCQ_EXP_NT_XLOAD mark the stream's accesses non-temporal.
 #ifdef MCQ_EXP_HOT_LOADS
     __device__ __forceinline__ uint32_t* lword(int idx) const { return word(idx & 63); }
 #else
@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3];
                 if (upkeep_now) upkeep();  // while those reads are in flight
                 const uint32_t vqi = wq & maskQ;
-                qi = (int)(vqi <= mQ ? vqi : 0u);  // an unused attempt must still index inside the queen table
+                qi = (int)min(vqi, mQ);  // (a used attempt has vqi <= mQ; an unused one must still index inside the queen table)
                 oldp = qn[qi];
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN), pc = (int)(w3 & maskN) & 31;
                 const uint32_t cw1 = colw[__mul24(pa, N) + pb];  // word index < 2^10: inside the workgroup's LDS
@@ -1497,20 +1497,17 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             auto append_entry = [&]() {
                 stage[e & 15] = (uint32_t)E | (reduced ? 0x40000000u | (acc << 31) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
                 if ((e & 15) == flush_at) {  // one aligned 64-byte segment per chain (flush_at = 15, or out of reach without a trace)
-#ifdef MCQ_EXP_NT_TRACE
-                    if constexpr (WPL == 4) {
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
-                    }
-#else
-                    if constexpr (WPL == 4) *(uint4*)hist_at(e - 15) = *(const uint4*)(stage + gl * 4);
-#endif
-                    else if constexpr (WPL == 2) *(uint2*)hist_at(e - 15) = *(const uint2*)(stage + gl * 2);
-                    else *hist_at(e - 15) = (int)stage[gl];
+                    // non-temporal: the trace is written once and never read here, so its lines should not push the MT19937 state's
+                    // lines out of the L2 (reads 68.0 -> 65.6 B/move, time unchanged; tools/nt_trace_experiment.sh)
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    if constexpr (WPL == 4) __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
+                    else if constexpr (WPL == 2) __builtin_nontemporal_store(*(const u32x2*)(stage + gl * 2), (u32x2*)hist_at(e - 15));
+                    else __builtin_nontemporal_store((int)stage[gl], hist_at(e - 15));
                 }
                 if ((e & 31) == 0) {
                     cold[C_N_ACC] += __popc(accw);  // accepted moves are counted from the bit words
-                    if (have_bits && gl == 0) *bits_at((e >> 5) - 1) = accw;
+                    if (have_bits && gl == 0) __builtin_nontemporal_store(accw, bits_at((e >> 5) - 1));
                     accw = 0;
 #ifndef MCQ_PACE_MASK
 #define MCQ_PACE_MASK 63
