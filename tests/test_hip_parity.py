@@ -129,6 +129,20 @@ def test_trace_none_matches_trace_i32():
     util.assert_results_equal(full, lean, "trace i32 vs none", trace=False)
 
 
+def test_default_lane_choice_never_changes_a_result():
+    """lanes_per_chain = 0 lets the library choose (4 for boards up to N = 12, 8 for a launch too small to fill the SIMDs at 4,
+    8 beyond and for full_3d): whatever it chooses equals every explicit choice."""
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    for N, mode, n_chains in ((12, "board", 48), (12, "board", 20000), (8, "board", 100), (12, "full_3d", 40)):
+        n_steps = 400 if n_chains > 1000 else 1500
+        seeds = abi.seeds_for(31 + N, n_chains)
+        ref, _ = mcq_amd._lib.run_host(abi.make_params(N, n_steps, "random", sp, n_chains, mcmc_type=mode, early_stop_patience=200), seeds)
+        for lanes in LANES:
+            got, _ = mcq_amd._lib.run_host(abi.make_params(N, n_steps, "random", sp, n_chains, mcmc_type=mode, early_stop_patience=200,
+                                                           lanes_per_chain=lanes), seeds)
+            util.assert_results_equal(ref, got, f"default lanes vs G={lanes}: N={N} {mode} n_chains={n_chains}")
+
+
 def test_ragged_chain_counts_and_tail_blocks():
     """n_chains not a multiple of the chains per wavefront, n_steps around the 16/32/64-entry block edges."""
     sp = {"type": "constant", "beta_const": 1.5}
