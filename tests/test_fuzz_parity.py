@@ -2,6 +2,8 @@
 Small runs (the oracle stays under a second each) over the whole parameter space: every N, both modes, the three
 initial states, the five schedules with ordinary and odd beta values, early stopping, all lane widths, the three trace
 modes' shared outputs, ragged chain counts and lengths around the flush boundaries (16 / 32 / 64 steps)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,11 +12,15 @@ from mcq_amd import abi
 from oracle import oracle
 from tests import util
 
-N_CASES = 400
+# Soak runs on demand: MCQ_FUZZ_CASES / MCQ_FUZZ_SEED / MCQ_FUZZ_LONG=1 (longer chains) widen the same generator;
+# the defaults are what the suite runs.
+N_CASES = int(os.environ.get("MCQ_FUZZ_CASES", "400"))
+FUZZ_SEED = int(os.environ.get("MCQ_FUZZ_SEED", "20251004"))
+FUZZ_LONG = os.environ.get("MCQ_FUZZ_LONG", "") == "1"
 
 
 def _cases():
-    rng = np.random.default_rng(20251004)
+    rng = np.random.default_rng(FUZZ_SEED)
     scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
     out = []
     for c in range(N_CASES):
@@ -33,6 +39,8 @@ def _cases():
                 lo, hi = hi, lo  # cooling and heating
             sp = {"type": st, "beta_start": lo, "beta_end": hi}
         n_steps = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 257, 400]))
+        if FUZZ_LONG and rng.random() < 0.3:
+            n_steps = int(rng.choice([1500, 3000, 5000]))
         n_chains = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24]))
         patience = None
         if mode == "board" and rng.random() < 0.35:
