@@ -20,6 +20,7 @@ Other BASELINE configs, same contract, selected with --config:
 c4 / c5 run through the drivers' own engine (jobs.JobSet): every cell / pair sharded over the ranks, one packed all-reduce.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1        (starts its own ranks: the line below, as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -79,12 +80,27 @@ def usable_cpus():
     return n
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes (one per GPU, the same command
+    line under torch.distributed.run), let rank 0's JSON line through on stdout and return the children's status.  This process
+    has not imported torch or touched the GPU, and it never execs: the ranks are children."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def init_dist(args, torch):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     # one rank per GPU; MCQ_BENCH_BACKEND=gloo (testing only) lets several ranks share a GPU and reduces on the host
     backend = os.environ.get("MCQ_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count())
@@ -358,7 +374,10 @@ def main():
     args = ap.parse_args()
     if args.chains is None:
         args.chains = 65536 if args.config in ("c2", "c3") else 1024
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # read when the HIP runtime initialises: before torch is imported (see _lib.py)
     import torch
 
     import mcq_amd

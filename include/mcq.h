@@ -58,7 +58,7 @@ extern "C" {
 /* random stream */
 #define MCQ_RNG_MT19937_NUMPY 0 /* NumPy legacy global RandomState: bit-parity with the reference */
 #define MCQ_RNG_PHILOX4X32_10 1 /* counter-based fast mode, NOT a stream of the reference: word w of chain r is
-                                   philox4x32-10(counter = (w / 4, 0, 0, 0), key = (seeds[r], 0))[w % 4], consumed with the same
+                                   philox4x32-10(counter = (low 32 bits of w / 4, high bits of w / 4, 0, 0), key = (seeds[r], 0))[w % 4], consumed with the same
                                    rules as the NumPy stream (masked rejection, 53-bit doubles, Fisher-Yates); no generator state
                                    lives in memory.  Results equal the oracle's in the same mode, not the reference's. */
 

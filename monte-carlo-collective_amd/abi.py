@@ -29,6 +29,7 @@ FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
 
 MIN_N, MAX_N = 2, 32
+MAX_HIST_STRIDE = 1 << 24  # a full trace row (hist_stride entries) must stay below this: include/mcq.h
 
 
 class Schedule(C.Structure):
@@ -319,8 +320,17 @@ def copy_params(params):
 
 def host_beta_table(params):
     """float64 [n_sets][n_steps] of a Params built by make_params / make_params_sets, or None when the schedules are not
-    known on the Python side (a hand-filled struct: the device then evaluates them itself)."""
-    sch = getattr(params, "_schedules", None)
-    if not sch or params.n_steps <= 0:
+    known on the Python side (`_schedules` absent or None: a hand-filled struct -- the device then evaluates them itself).
+    The values are derived from the struct's own fields (sched / beta_* and sets[t]), the ones the library would read, so a
+    Params edited after make_params runs the schedule it now describes, not the one it was built with."""
+    if not getattr(params, "_schedules", None) or params.n_steps <= 0:
         return None
+    names = {v: k for k, v in SCHED.items()}
+
+    def as_dict(s):
+        if s.sched not in names:
+            raise ValueError(f"Unknown betta_scheduling type: {s.sched}")
+        return {"type": names[s.sched], "beta_const": float(s.beta_const), "beta_start": float(s.beta_start), "beta_end": float(s.beta_end)}
+
+    sch = [as_dict(params.sets[t]) for t in range(int(params.n_sets))] if params.n_sets > 1 else [as_dict(params)]
     return np.ascontiguousarray(np.stack([beta_values(sp, params.n_steps) for sp in sch]))

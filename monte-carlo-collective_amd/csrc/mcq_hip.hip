@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 stage[e & 15] = (uint32_t)E | (reduced ? 0x40000000u | (acc << 31) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
                 if ((e & 15) == flush_at) {  // one aligned 64-byte segment per chain (flush_at = 15, or out of reach without a trace)
                     // non-temporal: the trace is written once and never read here, so its lines should not push the MT19937 state's
-                    // lines out of the L2 (reads 68.0 -> 65.6 B/move, time unchanged; tools/nt_trace_experiment.sh)
+                    // lines out of the L2 (reads 68.0 -> 65.6 B/move, time unchanged; profiles/r02_nt_trace_experiment.txt)
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                     if constexpr (WPL == 4) __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
@@ -1758,7 +1758,7 @@ int chain_lds_words_for(int N, int mode, bool narrow) {
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
     // The chains of a wavefront make many accesses at the SAME offset of their slices (history staging, cold scalars, ring appends):
     // a stride of 4 mod 8 words puts the 8 chains of a 32-lane access group on 8 different banks; 0 mod 8 would serialise them
-    // (A/B on the headline problem, same box: profiles/r02_lds_conflicts.txt).
+    // (A/B on the headline problem, same box: profiles/r02_lds_stride_ab.txt, r02_lds_stride_pmc.txt).
 #ifdef MCQ_EXP_LDS_STRIDE_0MOD8  // timing experiment (tools/exp_build.sh): the conflicting stride, for the A/B in profiles/
     w = (w + 7) & ~7;
 #else

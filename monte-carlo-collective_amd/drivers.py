@@ -29,6 +29,7 @@ import os
 
 import numpy as np
 
+from . import abi
 from . import distributed as dm
 from . import experiments as ex
 from . import jobs as jb
@@ -43,10 +44,15 @@ def _runner_or_default(runner):
 
 def _want(histories, jobs, dist, need_steps):
     """`histories` in (True, False, "auto") -> jobs.JobSet's `want`."""
+    # a full trace row holds at most abi.MAX_TRACE_ENTRIES entries (include/mcq.h: hist_stride < 2^24); the reference takes any
+    # n_steps, so longer runs go through the on-device statistics instead of failing inside the library
+    fits = all(abi.hist_stride_for(j["n_steps"]) < abi.MAX_HIST_STRIDE for j in jobs)
     if histories == "auto":
         total = sum(j["n_runs"] * (j["n_steps"] + 1) * 4 for j in jobs)
-        histories = dm.rank_world(dist)[1] == 1 and total <= HISTORY_BYTES_AUTO
+        histories = dm.rank_world(dist)[1] == 1 and total <= HISTORY_BYTES_AUTO and fits
     if histories:
+        if not fits:
+            raise ValueError(f"full histories hold at most {abi.MAX_HIST_STRIDE - 64} steps per chain; use histories=False (on-device statistics) for longer runs")
         return "histories"
     return "stats" if need_steps else "summary"
 

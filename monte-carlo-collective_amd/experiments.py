@@ -6,7 +6,6 @@ csrc/ through the C-ABI of include/mcq.h -- there is no process pool and no CPU 
 
     from mcq_amd.experiments import run_experiment, build_schedule_from_params
 """
-import math
 import time
 
 import numpy as np

@@ -61,3 +61,50 @@ def test_rccl_path_single_rank():
     assert rccl["n_gpus"] == 1
     for k in ("min_energy", "mean_best_energy", "acceptance_rate"):
         assert rccl[k] == one[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("config", ["c2", "c5"])
+def test_bench_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two child ranks (torch.distributed.run), relays
+    rank 0's line and returns their status; the job's results equal the one-rank run of the same chains."""
+    def run(gpus, chains, env):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0", "--n-steps", "3000",
+               "--chains", str(chains), "--no-cpu-baseline", "--config", config]
+        e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        out = subprocess.run(cmd, env=dict(e, **env), cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    per_gpu = 4096 if config == "c2" else 512
+    one = run(1, 2 * per_gpu, {})
+    two = run(2, per_gpu, {"MCQ_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["chains_total"] == one["config"]["chains_total"]
+    for k in ("min_energy", "acceptance_rate") + (("mean_best_energy",) if config == "c2" else ("min_energy_per_job",)):
+        assert two[k] == one[k], k
+
+
+def test_self_launch_command(monkeypatch):
+    """The parent of a self-launched multi-GPU bench never imports torch: it only builds the launcher's command line."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
