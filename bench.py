@@ -207,7 +207,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
                         + f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace is True else 'none' if trace is False else 'reduced'}"
                         + ("" if args.rng == "mt19937" else f" rng={args.rng} (NOT the reference's stream)"),
             "chains_total": total_chains,
-            "lanes_per_chain": int(run.p.lanes_per_chain) or int(mcq_amd._lib.lib().mcq_default_lanes_n(run.p.mode, run.p.N)),
+            "lanes_per_chain": mcq_amd._lib.effective_lanes(run.p),
             "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; one packed SUM all-reduce for the summary",
         },
         "min_energy": sm["min_best"],
@@ -333,6 +333,7 @@ def bench_jobs(args, torch, mcq_amd, dist, rank, world, red_dev):
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32+f64", "data": "synthetic (seeded initial boards, the reference's seed derivations; MT19937 NumPy-legacy stream)",
         "config": {"workload": what, "chains_total": chains * len(jobs), "launches_per_rank": len(js.launches),
+                   "lanes_per_chain": {f"N={int(la.run.p.N)}": mcq_amd._lib.effective_lanes(la.run.p) for la in js.launches},
                    "parallelism": f"every cell / pair sharded over {world} GPU(s); one packed SUM all-reduce of {js.total_words} int64 words"},
         "min_energy": min(m for m in mins if m is not None),
         "min_energy_per_job": mins,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCQ_ABI_VERSION 3
+#define MCQ_ABI_VERSION 4
 
 /* error codes */
 #define MCQ_OK 0
@@ -120,6 +120,22 @@ typedef struct mcq_params {
      * does: abi.host_beta_table).  mcq_run_device: DEVICE pointer; mcq_run_host: HOST pointer.  NULL: computed on the device
      * (exact for constant / linear; the other three within 2^-51 * max(|beta_start|, |beta_end|) of the reference's value). */
     const double* beta_table;
+    /* Replica exchange (parallel tempering) between the chains of a launch -- NOT a mode of the reference (its report, section VI,
+     * names better moves as future work), never a default, results equal the oracle's in the same mode.
+     * exchange_every = K > 0 turns it on: chains [g * R, (g + 1) * R), R = exchange_replicas (2, 4, 8 or 16; n_chains and
+     * chains_per_set are multiples of R), form one ladder.  Chain r starts on rung r % R; a chain on rung t runs every step s
+     * at beta(s) * exchange_ladder[t] (one float64 multiply; beta(s) from the schedule / beta_table as without exchange).
+     * After every K-th step (steps K-1, 2K-1, ... of the run, n = (s + 1) / K = 1, 2, ...) the rungs (t, t + 1) with
+     * t = (n & 1), (n & 1) + 2, ... <= R - 2 are offered a swap: with a, b the chains on rungs t, t + 1,
+     *     x = (beta_a - beta_b) * (double)(E_a - E_b),   beta_a = beta(s) * ladder[t],  beta_b = beta(s) * ladder[t + 1],
+     * the chain on rung t draws u = random() from ITS stream (two words, right after its step-s words; always drawn) and the two
+     * chains trade rungs iff u < min(1, exp(x)) -- the reference's accept rule (experiments.py:326-327) on the pair.  States,
+     * energies and histories stay with their chains; only the rung (hence beta) moves.  Needs patience < 0 (no early stop) and
+     * trace != REDUCED. */
+    int64_t exchange_every;        /* 0 = off */
+    int32_t exchange_replicas;     /* R */
+    int32_t reserved0;
+    const double* exchange_ladder; /* HOST pointer (also for mcq_run_device), R multipliers */
 } mcq_params;
 
 /*
@@ -148,6 +164,9 @@ typedef struct mcq_outputs {
     int64_t* step_accepted;  /* chains whose step e - 1 was accepted (entry 0: 0); includes the step at which a chain stopped
                                 early, which is executed and listed in accepted_steps but appends no entry (experiments.py:329-353) */
     int64_t* step_count;     /* chains whose history has entry e (< n_chains only after early stops)    */
+    /* exchange_every > 0 only, optional [n_chains] each: */
+    int32_t* exchange_rung;  /* the rung the chain ends on */
+    int64_t* n_exchanges;    /* accepted swaps the chain took part in */
 } mcq_outputs;
 
 /* ---- exported by libmcq_hip.so ------------------------------------------------------------ */
@@ -157,10 +176,16 @@ const char* mcq_last_error(void);
 int mcq_device_count(void);
 
 /* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 12 and 8 beyond, full_3d 8
- * (mcq_default_lanes: the value for small boards).  A board launch too small to give every SIMD a wavefront at 4 lanes per
- * chain (n_chains / 16 < 4 x compute units) runs at 8.  The lane count never changes a result. */
+ * (mcq_default_lanes: the value for small boards).  A board launch that leaves the device less than half full runs at twice or
+ * four times the lanes while it stays under two wavefronts per SIMD (N >= 20: at most 8); with replica exchange a ladder must
+ * fit one wavefront.  mcq_effective_lanes tells.  The lane count never changes a result. */
 int32_t mcq_default_lanes(int32_t mode);
 int32_t mcq_default_lanes_n(int32_t mode, int32_t N);
+/* the lane count a launch with these parameters really runs with (lanes_per_chain, or the default above and its small-launch
+ * rule, which looks at the current device); 0 on bad arguments */
+int32_t mcq_effective_lanes(const mcq_params* p);
+/* SIMDs of the current device (4 per compute unit; 1024 when no device answers): what the small-launch rule compares with */
+int32_t mcq_device_simds(void);
 
 /* bytes of one chain's state record in best_state / final_state; 0 on bad arguments */
 size_t mcq_state_bytes(int32_t N, int32_t mode);

@@ -80,6 +80,9 @@ def lib():
         L.mcq_default_lanes.argtypes = [C.c_int32]
         L.mcq_default_lanes_n.restype = C.c_int32
         L.mcq_default_lanes_n.argtypes = [C.c_int32, C.c_int32]
+        L.mcq_effective_lanes.restype = C.c_int32
+        L.mcq_effective_lanes.argtypes = [C.POINTER(abi.Params)]
+        L.mcq_device_simds.restype = C.c_int32
         L.mcq_state_bytes.restype = C.c_size_t
         L.mcq_state_bytes.argtypes = [C.c_int32, C.c_int32]
         L.mcq_workspace_bytes.restype = C.c_size_t
@@ -115,6 +118,11 @@ def _check(rc):
 
 def device_count():
     return lib().mcq_device_count()
+
+
+def effective_lanes(params):
+    """Lanes of a wavefront per chain a launch with these parameters runs with on the current device."""
+    return int(lib().mcq_effective_lanes(C.byref(params)))
 
 
 def beta_table_device(params):

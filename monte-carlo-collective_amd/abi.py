@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, EINVAL, EDEVICE, ENOMEM = 0, -1, -2, -3
 
@@ -67,6 +67,10 @@ class Params(C.Structure):
         ("chains_per_set", C.c_int64),
         ("sets", C.POINTER(Schedule)),
         ("beta_table", C.c_void_p),
+        ("exchange_every", C.c_int64),
+        ("exchange_replicas", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("exchange_ladder", C.POINTER(C.c_double)),
     ]
 
 
@@ -88,6 +92,8 @@ class Outputs(C.Structure):
         ("step_sumsq", C.c_void_p),
         ("step_accepted", C.c_void_p),
         ("step_count", C.c_void_p),
+        ("exchange_rung", C.c_void_p),
+        ("n_exchanges", C.c_void_p),
     ]
 
 
@@ -109,6 +115,8 @@ OUTPUT_DTYPES = {
     "step_sumsq": np.int64,
     "step_accepted": np.int64,
     "step_count": np.int64,
+    "exchange_rung": np.int32,
+    "n_exchanges": np.int64,
 }
 
 
@@ -142,6 +150,9 @@ def output_shapes(p, trace=True, states=True):
         sb = state_bytes(p.N, p.mode)
         shapes["best_state"] = (n, sb)
         shapes["final_state"] = (n, sb)
+    if p.exchange_every > 0:
+        shapes["exchange_rung"] = (n,)
+        shapes["n_exchanges"] = (n,)
     return shapes
 
 
@@ -312,7 +323,7 @@ def copy_params(params):
     keep = getattr(params, "_sets_keepalive", None)
     if keep is not None:
         p._sets_keepalive = keep
-    for k in ("_schedules", "_beta_keepalive"):
+    for k in ("_schedules", "_beta_keepalive", "_ladder_keepalive"):
         if hasattr(params, k):
             setattr(p, k, getattr(params, k))
     return p
@@ -334,3 +345,20 @@ def host_beta_table(params):
 
     sch = [as_dict(params.sets[t]) for t in range(int(params.n_sets))] if params.n_sets > 1 else [as_dict(params)]
     return np.ascontiguousarray(np.stack([beta_values(sp, params.n_steps) for sp in sch]))
+
+
+def set_exchange(params, every, ladder):
+    """Turn on replica exchange (include/mcq.h: exchange_every / exchange_replicas / exchange_ladder) on a Params block:
+    every `every` steps neighbouring rungs of each ladder of len(ladder) consecutive chains are offered a swap of their beta
+    multipliers.  NOT a mode of the reference.  Returns params."""
+    lad = np.ascontiguousarray(ladder, dtype=np.float64)
+    if int(every) <= 0:
+        raise ValueError("exchange_every must be positive")
+    if lad.ndim != 1 or len(lad) not in (2, 4, 8, 16):
+        raise ValueError("the exchange ladder has 2, 4, 8 or 16 rungs")
+    if params.n_chains % len(lad) or (params.n_sets > 1 and params.chains_per_set % len(lad)):
+        raise ValueError("n_chains (and chains_per_set) must be multiples of the number of rungs")
+    params.exchange_every, params.exchange_replicas = int(every), len(lad)
+    params.exchange_ladder = lad.ctypes.data_as(C.POINTER(C.c_double))
+    params._ladder_keepalive = lad
+    return params

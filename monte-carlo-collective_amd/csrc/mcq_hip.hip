@@ -58,6 +58,7 @@
 #include "../../include/mcq.h"
 
 extern "C" int32_t mcq_default_lanes(int32_t mode);
+extern "C" int32_t mcq_default_lanes_n(int32_t mode, int32_t N);
 
 namespace {
 
@@ -137,6 +138,9 @@ struct KArgs {
     unsigned long long* red;  // trace == REDUCED: [RED_STRIPES][3][red_len] per-entry sums (E, E^2, accepted | chains << 32)
     long long red_len;
     unsigned long long* dbg;  // MCQ_STAMPS diagnostic build only: per-section cycle sums
+    long long exch_every;     // replica exchange: period in steps (0: off)
+    int exch_R;               // rungs of a ladder
+    const double* exch_ladder;  // [exch_R] beta multipliers per rung (workspace)
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -806,6 +810,20 @@ __device__ __forceinline__ int accept_exact(double beta, int dE, uint32_t w1, ui
     return 1;
 }
 
+// Replica exchange, the pair's decision (include/mcq.h): the chains on rungs t and t + 1 trade rungs iff u < min(1, exp(x)),
+// x = (beta_a - beta_b) (E_a - E_b), u from the two words the lower chain draws -- experiments.py:326-327 applied to the pair.
+// Returns bit 0 = swap, bit 1 = u within 4 ulp of the probability.
+__device__ __forceinline__ int exchange_decide(double beta_a, double beta_b, int dEab, uint32_t w1, uint32_t w2) {
+    const double x = (beta_a - beta_b) * (double)dEab;
+    const double u = ((double)(w1 >> 5) * 67108864.0 + (double)(w2 >> 6)) * 1.1102230246251565e-16;
+    const double e = exp(x);
+    if (e < 1.0) {
+        const long long d = __double_as_longlong(u) - __double_as_longlong(e);
+        return (u < e ? 1 : 0) | ((d < 0 ? -d : d) <= 4 ? 2 : 0);
+    }
+    return 1;  // min(1.0, e) == 1.0 > u
+}
+
 // LDS per chain: stage[16] | cold[4] | ring[64 + 32 mirrored] | board: heights bytes, pad (pad = (N+2)/4 words >= N-1 bytes) |
 //                full_3d: pad[full_pad], column words [Q], pad[full_pad], queens uint16 [Q]; column words are uint16 in the
 //                unrolled variants (N <= 16), uint32 otherwise
@@ -934,8 +952,10 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // first pass's plus multiples of N: with N known they become immediate offsets of the LDS reads instead of an addition each
 // (12 vector instructions of ~208 per step on the headline problem); instantiated for N = 12, the size of BASELINE configs 2 and 3,
 // and for config 5's N = 24 (8 lanes, reduced trace).
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0>
+// EXCH: replica exchange between the chains of a ladder (mcq_params.exchange_every > 0; never with PATIENCE or REDUCED).
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false>
 __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : 4) void mcq_sweep_kernel(KArgs a) {
+    static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
     WAVE_T0;
     // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
     const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);
@@ -1097,6 +1117,12 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
 #endif
     constexpr uint32_t LOW_WATER = MCQ_LOW_WATER;
 
+    // replica exchange: the chain's rung, the float32 image of its beta multiplier, accepted swaps; wave-uniform countdown and parity
+    int rung = EXCH ? grp % a.exch_R : 0, n_exch = 0;
+    float m32 = EXCH && active ? (float)a.exch_ladder[rung] : 1.0f;
+    int xcount = EXCH ? (int)(a.exch_every > 2147483647LL ? 2147483647LL : a.exch_every) : 0;
+    int xpar = 1;  // exchange n = 1, 2, ... offers the rung pairs (t, t + 1) with t = n & 1 (mod 2)
+
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
     int last_entry = n_steps;  // wave-uniform: the last history entry any chain of the wavefront can have reached
@@ -1113,7 +1139,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
         STAMP(0);  // loop overhead + previous step's tail
         const int step = ALL ? vstep : __builtin_amdgcn_readfirstlane(vstep);
         vstep = step + 1;
-        const float c32 = c32_tab[(uint32_t)step];  // exp(-beta dE) = exp2(dE * c32)  (unsigned index: a scalar load with a 32-bit offset register)
+        const float c32s = c32_tab[(uint32_t)step];  // exp(-beta dE) = exp2(dE * c32)  (unsigned index: a scalar load with a 32-bit offset register)
+        const float c32 = EXCH ? c32s * m32 : c32s;  // replica exchange: the chain runs at beta(step) * ladder[rung]
         // what closes a step for the whole wavefront (stopped and idle lanes included): REDUCED adds every 16th block of entries
         // to the accumulators.  SOME_INACTIVE = false: every lane is a live chain (the ALL form's common path).
         auto end_of_step = [&](auto some_inactive) __attribute__((always_inline)) {
@@ -1139,6 +1166,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             uint32_t oldp = 0;
             uint32_t uw1 = 0, uw2 = 0;   // the two words of random()
             int stage_no = 0;
+            int redraw_from = -1;        // board: words to skip when only new_k has to be drawn again
             // stream upkeep runs for every chain of the wavefront together (cadence: see LOW_WATER above)
             auto upkeep = [&]() {
                 STAMP(0);
@@ -1255,6 +1283,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 asm volatile("" : "+v"(fifth));  // (keeps it one compare: the compiler would take the select apart into mask logic again)
                 batched = fifth < draw_limit;
                 rng.consume(batched ? (uint32_t)kp + 3u : 0u);
+                redraw_from = (uint32_t)p5 < draw_limit ? p5 + 1 : -1;  // (dead outside the rare path below)
             } else {
                 // q = first word accepted for randint(0, Q); then a candidate (i, j, k) triple from the words accepted for
                 // randint(0, N) after it, and a second triple when the first cell is occupied; the uniform's two words follow the
@@ -1301,6 +1330,15 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             }
             if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
                 if (!batched) {
+                    if constexpr (MODE == MCQ_MODE_BOARD) {
+                        // Three candidates in a row equal to old_k, all of them inside the generated words (1/N^3 per chain: 4 % at
+                        // N = 3, so 45 % of the steps of a 16-chain wavefront): i, j and old_k stand, and the word-by-word draw goes
+                        // on behind the third candidate instead of starting the proposal over.
+                        if (pc == old_k && redraw_from >= 0) {
+                            rng.consume((uint32_t)redraw_from);
+                            stage_no = 2;
+                        }
+                    }
                     sequential();
                     if constexpr (EARLY_PROBES) load_probes();
                 }
@@ -1457,7 +1495,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             uint32_t acc = (xneg ? d : -1.0f) < 0.0f ? 1u : 0u;  // 0 / 1 in a vector register: the rare branch below may rewrite it
             if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
                 if (exact) {
-                    const int r = accept_exact(beta_tab[step], dE, uw1, uw2);
+                    const int r = accept_exact(EXCH ? beta_tab[step] * a.exch_ladder[rung] : beta_tab[step], dE, uw1, uw2);
                     acc = (uint32_t)r & 1u;
                     if (r >> 1) cold[C_TIES] += 1;
                 }
@@ -1551,6 +1589,39 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             } else {
                 append_entry();
             }
+            if constexpr (EXCH) {
+                if (--xcount == 0) {  // wave-uniform: every K-th step
+                    xcount = (int)(a.exch_every > 2147483647LL ? 2147483647LL : a.exch_every);
+                    const int R = a.exch_R;
+                    const int cl = grp & (R - 1);                  // this chain's place in its ladder (R is a power of two dividing 64 / G)
+                    const int lb = (grp - cl) * G + gl;            // the same lane of the ladder's first chain
+                    const bool lower = ((rung ^ xpar) & 1) == 0;   // pairs (t, t + 1), t = xpar (mod 2): the lower rung decides
+                    xpar ^= 1;
+                    const int prt = lower ? rung + 1 : rung - 1;   // the partner's rung
+                    const bool paired = (unsigned)prt < (unsigned)R;
+                    // rung -> chain: every chain drops its place at the lane group of its rung (the rungs of a ladder are a
+                    // permutation: no two lanes write one destination), then reads who sits on the partner's rung
+                    const int on_rung = __builtin_amdgcn_ds_permute((lb + rung * G) * 4, cl);
+                    const int pcl = __builtin_amdgcn_ds_bpermute((lb + (paired ? prt : rung) * G) * 4, on_rung);
+                    const int pE = __builtin_amdgcn_ds_bpermute((lb + pcl * G) * 4, E);
+                    // the lower chain draws random() from its stream, always (like the uniform of a step): two ready words
+                    while (wave_any(rng.gen - rng.pos < 2u)) upkeep();
+                    const uint32_t xw1 = ring[rng.pos & (RING - 1)], xw2 = ring[(rng.pos + 1u) & (RING - 1)];
+                    int dec = 0;
+                    if (lower && paired) {
+                        rng.consume(2u);
+                        const double b = beta_tab[step];
+                        dec = exchange_decide(b * a.exch_ladder[rung], b * a.exch_ladder[prt], E - pE, xw1, xw2);
+                        if (dec >> 1) cold[C_TIES] += 1;
+                    }
+                    const int pdec = __builtin_amdgcn_ds_bpermute((lb + pcl * G) * 4, dec);
+                    if (paired && (((lower ? dec : pdec) & 1) != 0)) {
+                        rung = prt;
+                        n_exch++;
+                        m32 = (float)a.exch_ladder[rung];
+                    }
+                }
+            }
         }
         end_of_step(std::integral_constant<bool, !ALL>());
         if constexpr (PATIENCE && !ALL) {
@@ -1610,6 +1681,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             if (a.out.steps_to_best) a.out.steps_to_best[chain] = cold[C_BEST_STEP];
             if (a.out.n_accepted) a.out.n_accepted[chain] = cold[C_N_ACC];
             if (a.out.near_ties) a.out.near_ties[chain] = cold[C_TIES];
+            if (EXCH && a.out.exchange_rung) a.out.exchange_rung[chain] = rung;
+            if (EXCH && a.out.n_exchanges) a.out.n_exchanges[chain] = n_exch;
         }
         if (a.out.final_state) {
             uint8_t* fo = a.out.final_state + chain * (long long)state_bytes;
@@ -1732,6 +1805,16 @@ int validate(const mcq_params* p) {
             if (p->sets[t].init_plus1 < 0 || p->sets[t].init_plus1 > MCQ_INIT_KLARNER + 1) return fail(MCQ_EINVAL, "Unknown init_mode in sets");
         }
     }
+    if (p->exchange_every < 0) return fail(MCQ_EINVAL, "negative exchange_every");
+    if (p->exchange_every > 0) {
+        const int R = p->exchange_replicas;
+        if (R != 2 && R != 4 && R != 8 && R != 16) return fail(MCQ_EINVAL, "exchange_replicas must be 2, 4, 8 or 16");
+        if (!p->exchange_ladder) return fail(MCQ_EINVAL, "exchange_every > 0 without exchange_ladder");
+        if (p->n_chains % R != 0 || (p->n_sets > 1 && p->chains_per_set % R != 0)) return fail(MCQ_EINVAL, "n_chains (and chains_per_set) must be multiples of exchange_replicas");
+        if (p->mode == MCQ_MODE_BOARD && p->patience >= 0 && p->patience <= p->n_steps) return fail(MCQ_EINVAL, "replica exchange needs early stopping off (early_stop_patience None)");
+        if (p->trace == MCQ_TRACE_REDUCED) return fail(MCQ_EINVAL, "replica exchange runs with trace none or i32");
+        if (p->lanes_per_chain != 0 && 64 / p->lanes_per_chain < R) return fail(MCQ_EINVAL, "lanes_per_chain too wide: a ladder of exchange_replicas chains must fit one wavefront");
+    }
     return MCQ_OK;
 }
 
@@ -1747,6 +1830,7 @@ long long red_len_for(const mcq_params* p) { return (p->n_steps + 1 + 31) & ~31L
 size_t red_set_bytes(const mcq_params* p) { return p->trace == MCQ_TRACE_REDUCED ? (size_t)RED_STRIPES * 3 * red_len_for(p) * 8 : 0; }
 size_t red_bytes(const mcq_params* p) { return n_sets_of(p) * red_set_bytes(p); }
 constexpr size_t PACE_BYTES = 2048 * 16 * 4;  // 8 XCC x 4 SE x 16 CU x 4 SIMD rows of 16 wave slots
+constexpr size_t LADDER_BYTES = 16 * 8;       // replica exchange: the beta multipliers of a ladder
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
 // side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
@@ -1798,7 +1882,9 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->tab_stride = (long long)tab_stride_for(p);
     a->red_set_stride = (long long)(red_set_bytes(p) / 8);
     a->pace = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p));
-    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES);
+    a->exch_every = p->exchange_every, a->exch_R = p->exchange_every > 0 ? p->exchange_replicas : 1;
+    a->exch_ladder = (const double*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES);
+    a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES);
     a->seeds = seeds, a->out = *out;
 #if defined(MCQ_STAMPS) || defined(MCQ_WAVE_TIMES)
     a->dbg = g_dbg;
@@ -1814,7 +1900,27 @@ int device_simds() {
     return 4 * cus;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0>
+// lanes of a wavefront per chain a launch runs with: the caller's choice, or the default for the board size -- except that a board
+// launch on its own that leaves the device less than half full (under two wavefronts per SIMD a wavefront is bound by its own
+// latency, and a step is shorter with more lanes: profiles/r03_lane_table.txt) is spread over twice, then four times as many
+// wavefronts while it stays there.  Boards from N = 20 stop at 8 lanes (16 take the run-time probe loop and are slower).
+// (A caller that runs several launches side by side knows better and says so: jobs.plan_lanes.)
+int effective_lanes(const mcq_params* p) {
+    int G = p->lanes_per_chain;
+    if (!G) {
+        G = mcq_default_lanes_n(p->mode, p->N);
+        if (p->mode == MCQ_MODE_BOARD) {
+            const long long room = 2LL * device_simds();
+            const int top = p->N >= 20 ? 8 : 16;
+            while (G < top && (p->n_chains * (2 * G) + 63) / 64 <= room) G *= 2;
+        }
+        // replica exchange: a ladder lives in one wavefront (its chains swap through cross-lane moves, no barrier)
+        if (p->exchange_every > 0 && 64 / G < p->exchange_replicas) G = 64 / p->exchange_replicas;
+    }
+    return G;
+}
+
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -1824,9 +1930,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -1856,8 +1962,27 @@ int launch_sweep_philox(const KArgs& a, hipStream_t s) {
     }
 }
 
+// Replica exchange (never a default, not a mode of the reference): the run-time probe loop for every size, plus the two
+// single_N shapes of BASELINE (board N = 12 at 4 lanes, full_3d N = 12 at 8) with their unrolled steps.
+template <int MODE, int G>
+int launch_sweep_exchange(const KArgs& a, hipStream_t s) {
+    if (a.rng == MCQ_RNG_PHILOX4X32_10) return launch_sweep<MODE, G, false, 0, false, true, 0, true>(a, s);
+    if constexpr (MODE == MCQ_MODE_BOARD && G == 4) {
+        if (a.N == 12) return launch_sweep<MODE, G, false, 3, false, false, 12, true>(a, s);
+    }
+    if constexpr (MODE == MCQ_MODE_FULL3D && G == 8) {
+        if (a.N == 12) {
+            KArgs b = a;
+            b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+            return launch_sweep<MODE, G, false, 3, false, false, 12, true>(b, s);
+        }
+    }
+    return launch_sweep<MODE, G, false, 0, false, false, 0, true>(a, s);
+}
+
 template <int MODE, int G>
 int launch_sweep_g(const KArgs& a, hipStream_t s) {
+    if (a.exch_every > 0) return launch_sweep_exchange<MODE, G>(a, s);
     if (a.rng == MCQ_RNG_PHILOX4X32_10) return launch_sweep_philox<MODE, G>(a, s);
     if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
         if constexpr (G == 8) {  // N <= 16: 16-bit column words, four lanes around each of the two cells
@@ -1972,6 +2097,8 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
 
     if (a.red) HIP_TRY(hipMemsetAsync(a.red, 0, red_bytes(p), s));
     HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
+    if (p->exchange_every > 0)  // 16 doubles at most, from the caller's (host) array
+        HIP_TRY(hipMemcpyAsync((void*)a.exch_ladder, p->exchange_ladder, (size_t)p->exchange_replicas * 8, hipMemcpyHostToDevice, s));
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     {  // behind the state: the permutation array of np.random.choice (full_3d random init), then the E0 line counters
         const size_t D = 2 * (size_t)p->N - 1, lines = ((3 * (size_t)a.Q + 6 * p->N * D + 4 * D * D + 3) / 4) * 4;
@@ -2020,13 +2147,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
 
-    int G = p->lanes_per_chain;
-    if (!G) {
-        G = mcq_default_lanes_n(p->mode, p->N);
-        // a launch that cannot give every SIMD a wavefront at 4 lanes per chain is spread over twice as many at 8, each with a
-        // shorter step (config 4 on its per-GPU shape, 18 concurrent launches of 3 072 chains: 322 -> 290 ms)
-        if (p->mode == MCQ_MODE_BOARD && G == 4 && (p->n_chains + 15) / 16 < device_simds()) G = 8;
-    }
+    const int G = effective_lanes(p);
     rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
     if (a.red) {
@@ -2061,6 +2182,10 @@ int32_t mcq_default_lanes(int32_t mode) { return mode == MCQ_MODE_BOARD ? 4 : 8;
 // beyond (65 536 chains x 20 000 steps: N = 13 42 ms against 49 ms, N = 16 42 / 52, N = 20 56 / 70, N = 24 56 / 73); full_3d: 8
 int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_BOARD && N > 12 ? 8 : mcq_default_lanes(mode); }
 
+int32_t mcq_effective_lanes(const mcq_params* p) { return validate(p) == MCQ_OK ? effective_lanes(p) : 0; }
+
+int32_t mcq_device_simds(void) { return device_simds(); }
+
 size_t mcq_state_bytes(int32_t N, int32_t mode) {
     if (N < MCQ_MIN_N || N > MCQ_MAX_N) return 0;
     return mode == MCQ_MODE_BOARD ? (size_t)N * N : (size_t)3 * N * N;
@@ -2068,7 +2193,7 @@ size_t mcq_state_bytes(int32_t N, int32_t mode) {
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
-    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -2224,6 +2349,8 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
         {(void**)&d.steps_to_best, out->steps_to_best, n * 8},
         {(void**)&d.n_accepted, out->n_accepted, n * 8},
         {(void**)&d.near_ties, out->near_ties, n * 8},
+        {(void**)&d.exchange_rung, p->exchange_every > 0 ? out->exchange_rung : nullptr, n * 4},
+        {(void**)&d.n_exchanges, p->exchange_every > 0 ? out->n_exchanges : nullptr, n * 8},
         {(void**)&d.best_state, out->best_state, n * sb},
         {(void**)&d.final_state, out->final_state, n * sb},
         {(void**)&d.step_sum, p->trace == MCQ_TRACE_REDUCED ? out->step_sum : nullptr, n_sets_of(p) * (size_t)(p->n_steps + 1) * 8},

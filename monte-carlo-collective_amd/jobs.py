@@ -39,6 +39,58 @@ def _stopped_hist(hist_len, n_steps, xp, **kw):
     return xp.bincount(hl, minlength=n_steps + 1, **kw)[: n_steps + 1]
 
 
+# Step time of ONE board wavefront with the SIMD to itself, ms per 20 000 steps, by N and lanes per chain (4, 8, 16): the measure a
+# job list's lane plan and launch order are built on (tools/lane_table.py on one MI355X, profiles/r03_lane_table.txt).  Lone-wave
+# latency, not throughput: it ranks launches that run side by side below the device's capacity; above it the library default stands.
+_LONE_MS = {
+    2: (20.8, 17.3, 14.6), 3: (20.8, 17.3, 14.6), 4: (13.4, 13.0, 11.8), 5: (13.8, 12.9, 11.9), 6: (11.6, 11.6, 11.0), 7: (10.6, 11.0, 10.6),
+    8: (10.1, 10.7, 10.4), 9: (14.5, 12.7, 11.9), 10: (12.8, 11.4, 10.9), 11: (12.1, 10.9, 10.5), 12: (10.9, 10.6, 10.4),
+    13: (12.7, 10.4, 10.2), 14: (12.5, 10.3, 10.1), 15: (12.3, 10.2, 10.0), 16: (12.2, 10.1, 10.0), 17: (19.5, 17.0, 14.8),
+    18: (18.1, 16.0, 13.9), 19: (17.5, 15.3, 13.5), 20: (17.2, 14.9, 16.8), 21: (23.7, 14.7, 16.6), 22: (23.7, 14.6, 16.5),
+    23: (23.5, 14.5, 16.4), 24: (23.5, 14.4, 16.3),
+}
+WAVES_PER_SIMD = 4  # resident wavefronts per SIMD of the sweep kernels (their register budget)
+
+
+def lone_ms(N, lanes):
+    """Estimated lone-wavefront sweep time of a board launch per 20 000 steps."""
+    t = _LONE_MS.get(int(N), _LONE_MS[24])
+    return t[{4: 0, 8: 1, 16: 2}[int(lanes)]] * (max(int(N), 24) / 24.0)
+
+
+def plan_lanes(shapes, simds, default_lanes):
+    """Lanes per chain for launches that run side by side on one device.  `shapes`: one (N, n_chains, mode) per launch;
+    `default_lanes(mode, N)`: the library's choice for a device full of that launch.  The library picks lanes for a launch on
+    its own; a job list knows how many wavefronts its launches put on the device TOGETHER (capacity: WAVES_PER_SIMD per SIMD):
+      * start from the library defaults; if together they overflow the capacity but 4 lanes everywhere would fit, everything
+        runs at 4 -- one resident round beats a second one;
+      * while the device is less than half full (under two wavefronts per SIMD a wavefront is bound by its own latency and
+        further wavefronts cost the others next to nothing), the launch with the longest estimated step gets twice the lanes if
+        that shortens its step -- the job list ends when its slowest launch does.  Closer to the capacity more wavefronts slow
+        everybody down: measured on measure_min_energy_vs_N at 1 024 chains per cell, 4 lanes everywhere 199 ms, N = 3 at 16
+        lanes 215 ms (profiles/r03_lane_plan.txt).
+    full_3d launches keep the library default.  Returns the list of lane counts."""
+    cap = WAVES_PER_SIMD * int(simds)
+    waves = lambda n, g: (n + 64 // g - 1) // (64 // g)
+    total = lambda pl: sum(waves(n, g) for (_, n, _), g in zip(shapes, pl))
+    board = [m == abi.MODE_BOARD for _, _, m in shapes]
+    plan = [int(default_lanes(m, N)) for N, _, m in shapes]
+    if total(plan) > cap:
+        four = [4 if b else g for b, g in zip(board, plan)]
+        if total(four) <= cap:
+            plan = four
+    while 2 * total(plan) <= cap:
+        est = [lone_ms(N, g) if b else 0.0 for (N, _, _), g, b in zip(shapes, plan, board)]
+        i = max(range(len(plan)), key=lambda k: est[k], default=None)
+        if i is None or not board[i] or plan[i] == 16 or lone_ms(shapes[i][0], 2 * plan[i]) >= est[i]:
+            break
+        trial = plan[:i] + [2 * plan[i]] + plan[i + 1:]
+        if 2 * total(trial) > cap:
+            break
+        plan = trial
+    return plan
+
+
 class _Launch:
     """One DeviceRun and the jobs (schedule sets) it carries."""
 
@@ -77,17 +129,24 @@ class JobSet:
 
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device())
+        L = _lib.lib()
         groups = {}
         for i, j in enumerate(self.jobs):
             n = len(self.shards[i][0])
             key = (j["N"], j["n_steps"], j["mcmc_type"], j["early_stop_patience"], n)  # schedule, init mode and seeds may differ inside a launch
             batchable = n > 0 and n % 16 == 0 and j["schedule_params"] is not None
             groups.setdefault(key if batchable else ("single", i), []).append(i)
+        groups = {k: ids for k, ids in groups.items() if len(self.shards[ids[0]][0]) > 0}
+        lanes = {k: lanes_per_chain for k in groups}
+        if not lanes_per_chain and len(groups) > 0:  # the launches run side by side: choose their lane counts together
+            keys = list(groups)
+            shapes = [(self.jobs[groups[k][0]]["N"], len(self.shards[groups[k][0]][0]) * len(groups[k]),
+                       abi.mode_of(self.jobs[groups[k][0]]["mcmc_type"])) for k in keys]
+            lanes = dict(zip(keys, plan_lanes(shapes, L.mcq_device_simds(), L.mcq_default_lanes_n)))
         for key, ids in groups.items():
             j0 = self.jobs[ids[0]]
             n = len(self.shards[ids[0]][0])
-            if n == 0:
-                continue
+            lanes_per_chain = lanes[key]
             if len(ids) > 1:
                 p = abi.make_params_sets(j0["N"], j0["n_steps"], j0["init_mode"], [self.jobs[i]["schedule_params"] for i in ids], n,
                                          mcmc_type=j0["mcmc_type"], early_stop_patience=j0["early_stop_patience"], trace=self.trace,
@@ -101,8 +160,13 @@ class JobSet:
             la = _Launch(ids, run, n, n)
             la.stream = torch.cuda.Stream()
             self.launches.append(la)
-        # longest first (a step costs roughly N lane-operations per chain): the short launches then fill the tail of the long ones
-        self.launches.sort(key=lambda la: -(la.run.p.N * la.run.p.n_steps * la.run.p.n_chains))
+        # longest first, by the estimated time of one of its wavefronts: the launches that follow fill in behind it
+        def est(la):
+            p = la.run.p
+            g = _lib.effective_lanes(p)
+            return (lone_ms(p.N, g) if p.mode == abi.MODE_BOARD else 2.0 * lone_ms(p.N, 8)) * p.n_steps
+
+        self.launches.sort(key=lambda la: -est(la))
         self.buf = torch.zeros(self.total_words, dtype=torch.int64, device=self.device)
 
     def launch(self):

@@ -809,6 +809,217 @@ static int run_full_chain_fast(const job_t* jb, int64_t r) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Replica exchange (mcq_params.exchange_every > 0; include/mcq.h).  NOT a mode of the reference: its report (section VI) names
+ * better moves as future work; the swap uses the reference's accept rule (experiments.py:326-327) on a pair of chains.  Parity in
+ * this mode is HIP == this file.  The chains of a ladder advance in lockstep, so a chain is an object with a step function here;
+ * the step is the same restatement as run_board_chain / run_full_chain above (tests/test_exchange.py holds the two against each
+ * other with a ladder of ones and an exchange period beyond the run).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const mcq_params* p; /* the chain's set */
+    const mcq_outputs* o;
+    int64_t r;
+    int fast, N, Q;
+    rng_t rng;
+    int *h, *best_h;         /* board */
+    cell_t *q, *best_q;      /* full_3d */
+    uint8_t* occ;
+    uint8_t* cnt;            /* fast: line counters */
+    lines_t L;
+    int E, best;
+    int64_t best_step, accepted, ties, len;
+    int32_t* hist;
+    uint64_t* bits;
+    int rung;
+    int64_t n_exch;
+} xchain_t;
+
+static void xchain_free(xchain_t* c) {
+    free(c->h), free(c->q), free(c->occ), free(c->cnt);
+    c->h = NULL, c->q = NULL, c->occ = NULL, c->cnt = NULL;
+}
+
+static int xchain_init(xchain_t* c, const mcq_params* p, const mcq_outputs* o, const uint32_t* seeds, int64_t r, int fast, int rung) {
+    memset(c, 0, sizeof *c);
+    c->p = p, c->o = o, c->r = r, c->fast = fast, c->N = p->N, c->Q = p->N * p->N, c->rung = rung;
+    const int N = c->N, Q = c->Q;
+    rng_seed(&c->rng, p->rng, seeds[r]);
+    if (fast) {
+        c->cnt = (uint8_t*)malloc(lines_total(N));
+        if (!c->cnt) return MCQ_ENOMEM;
+        lines_setup(&c->L, N, c->cnt);
+    }
+    if (p->mode == MCQ_MODE_BOARD) {
+        c->h = (int*)malloc(sizeof(int) * (size_t)Q * 2);
+        if (!c->h) return MCQ_ENOMEM;
+        c->best_h = c->h + Q;
+        if (board_init(N, p->init, &c->rng, c->h) != 0) return MCQ_EINVAL;
+        if (fast) {
+            for (int t = 0; t < Q; t++) lines_add(&c->L, t / N, t % N, c->h[t], 1);
+            c->E = lines_energy(&c->L);
+        } else {
+            c->E = board_energy(N, c->h);
+        }
+        memcpy(c->best_h, c->h, sizeof(int) * (size_t)Q);
+    } else {
+        c->q = (cell_t*)malloc(sizeof(cell_t) * (size_t)Q * 2);
+        c->occ = (uint8_t*)malloc((size_t)N * N * N);
+        if (!c->q || !c->occ) return MCQ_ENOMEM;
+        c->best_q = c->q + Q;
+        if (full_init(N, p->init, &c->rng, c->q, c->occ) != 0) return MCQ_EINVAL;
+        if (fast) {
+            for (int t = 0; t < Q; t++) lines_add(&c->L, c->q[t].i, c->q[t].j, c->q[t].k, 1);
+            c->E = lines_energy(&c->L);
+        } else {
+            c->E = full_energy(Q, c->q);
+        }
+        memcpy(c->best_q, c->q, sizeof(cell_t) * (size_t)Q);
+    }
+    c->best = c->E, c->len = 1;
+    c->hist = o->energy_hist ? o->energy_hist + r * p->hist_stride : NULL;
+    c->bits = o->accept_bits ? o->accept_bits + r * p->bits_stride : NULL;
+    if (c->hist) c->hist[0] = c->E;
+    if (c->bits)
+        for (int64_t w = 0; w < p->bits_stride; w++) c->bits[w] = 0;
+    if (o->initial_energy) o->initial_energy[r] = c->E;
+    return MCQ_OK;
+}
+
+/* one Metropolis step at inverse temperature beta (experiments.py:308-358 / 218-258; no early stop in this mode) */
+static void xchain_step(xchain_t* c, int64_t step, double beta) {
+    const int N = c->N, Q = c->Q;
+    rng_t* rng = &c->rng;
+    int dE, acc;
+    if (c->p->mode == MCQ_MODE_BOARD) {
+        int* h = c->h;
+        int i = (int)mt_bounded(rng, (uint32_t)(N - 1));
+        int j = (int)mt_bounded(rng, (uint32_t)(N - 1));
+        int old_k = h[i * N + j];
+        int old_c = c->fast ? 0 : board_conflicts(N, h, i, j, old_k);
+        int new_k = (int)mt_bounded(rng, (uint32_t)(N - 1));
+        while (new_k == old_k) new_k = (int)mt_bounded(rng, (uint32_t)(N - 1));
+        if (c->fast) dE = lines_sum(&c->L, i, j, new_k) - lines_sum(&c->L, i, j, old_k) + 12;
+        else dE = board_conflicts(N, h, i, j, new_k) - old_c;
+        acc = accept_move(rng, beta, dE, &c->ties);
+        if (acc) {
+            if (c->fast) lines_add(&c->L, i, j, old_k, -1), lines_add(&c->L, i, j, new_k, 1);
+            h[i * N + j] = new_k;
+        }
+    } else {
+        cell_t* q = c->q;
+        int qi = (int)mt_bounded(rng, (uint32_t)(Q - 1));
+        cell_t od = q[qi], nw;
+        int old_c = c->fast ? 0 : full_conflicts(Q, q, qi, od);
+        for (;;) {
+            nw.i = (int)mt_bounded(rng, (uint32_t)(N - 1));
+            nw.j = (int)mt_bounded(rng, (uint32_t)(N - 1));
+            nw.k = (int)mt_bounded(rng, (uint32_t)(N - 1));
+            if (!c->occ[(nw.i * N + nw.j) * N + nw.k]) break;
+        }
+        if (c->fast) dE = (lines_sum(&c->L, nw.i, nw.j, nw.k) - full_attacks(od, nw)) - (lines_sum(&c->L, od.i, od.j, od.k) - 13);
+        else dE = full_conflicts(Q, q, qi, nw) - old_c;
+        acc = accept_move(rng, beta, dE, &c->ties);
+        if (acc) {
+            if (c->fast) lines_add(&c->L, od.i, od.j, od.k, -1), lines_add(&c->L, nw.i, nw.j, nw.k, 1);
+            c->occ[(od.i * N + od.j) * N + od.k] = 0;
+            c->occ[(nw.i * N + nw.j) * N + nw.k] = 1;
+            q[qi] = nw;
+        }
+    }
+    if (acc) {
+        if (c->bits) c->bits[step >> 6] |= 1ull << (step & 63);
+        c->E += dE;
+        c->accepted++;
+        if (c->E < c->best) {
+            c->best = c->E;
+            if (c->h) memcpy(c->best_h, c->h, sizeof(int) * (size_t)Q);
+            else memcpy(c->best_q, c->q, sizeof(cell_t) * (size_t)Q);
+            c->best_step = c->len;
+        }
+    }
+    if (c->hist) c->hist[c->len] = c->E;
+    c->len++;
+}
+
+static void xchain_finish(xchain_t* c) {
+    const mcq_outputs* o = c->o;
+    const int64_t r = c->r;
+    const int Q = c->Q;
+    if (o->hist_len) o->hist_len[r] = c->len;
+    if (o->steps_executed) o->steps_executed[r] = c->p->n_steps;
+    if (o->best_energy) o->best_energy[r] = c->best;
+    if (o->final_energy) o->final_energy[r] = c->E;
+    if (o->steps_to_best) o->steps_to_best[r] = c->best_step;
+    if (o->n_accepted) o->n_accepted[r] = c->accepted;
+    if (o->near_ties) o->near_ties[r] = c->ties;
+    if (o->exchange_rung) o->exchange_rung[r] = c->rung;
+    if (o->n_exchanges) o->n_exchanges[r] = c->n_exch;
+    for (int t = 0; t < Q; t++) {
+        if (c->h) {
+            if (o->best_state) o->best_state[r * Q + t] = (uint8_t)c->best_h[t];
+            if (o->final_state) o->final_state[r * Q + t] = (uint8_t)c->h[t];
+        } else {
+            if (o->best_state) {
+                uint8_t* d = o->best_state + ((size_t)r * Q + t) * 3;
+                d[0] = (uint8_t)c->best_q[t].i, d[1] = (uint8_t)c->best_q[t].j, d[2] = (uint8_t)c->best_q[t].k;
+            }
+            if (o->final_state) {
+                uint8_t* d = o->final_state + ((size_t)r * Q + t) * 3;
+                d[0] = (uint8_t)c->q[t].i, d[1] = (uint8_t)c->q[t].j, d[2] = (uint8_t)c->q[t].k;
+            }
+        }
+    }
+}
+
+/* one ladder: chains [g * R, (g + 1) * R) in lockstep */
+static int run_exchange_group(const job_t* jb, int64_t g) {
+    const mcq_params* p0 = jb->p;
+    const int R = p0->exchange_replicas;
+    const int64_t K = p0->exchange_every, r0 = g * R;
+    mcq_params ps = *p0; /* the ladder's set (chains_per_set is a multiple of R) */
+    if (p0->n_sets > 1) {
+        const int64_t t = r0 / p0->chains_per_set;
+        const mcq_schedule* sc = &p0->sets[t];
+        ps.sched = sc->sched, ps.beta_const = sc->beta_const, ps.beta_start = sc->beta_start, ps.beta_end = sc->beta_end;
+        if (sc->init_plus1) ps.init = sc->init_plus1 - 1;
+        if (ps.beta_table) ps.beta_table += t * ps.n_steps;
+    }
+    xchain_t ch[16];
+    int on_rung[16]; /* rung -> chain of the ladder */
+    int rc = MCQ_OK;
+    memset(ch, 0, sizeof ch);
+    for (int c = 0; c < R && rc == MCQ_OK; c++) {
+        rc = xchain_init(&ch[c], &ps, jb->out, jb->seeds, r0 + c, jb->fast, c);
+        on_rung[c] = c;
+    }
+    for (int64_t step = 0; step < ps.n_steps && rc == MCQ_OK; step++) {
+        const double beta = beta_at(&ps, step);
+        for (int c = 0; c < R; c++) xchain_step(&ch[c], step, beta * p0->exchange_ladder[ch[c].rung]);
+        if ((step + 1) % K != 0) continue;
+        const int64_t n = (step + 1) / K;
+        for (int t = (int)(n & 1); t + 1 < R; t += 2) {
+            xchain_t *a = &ch[on_rung[t]], *b = &ch[on_rung[t + 1]];
+            const double ba = beta * p0->exchange_ladder[t], bb = beta * p0->exchange_ladder[t + 1];
+            const double x = (ba - bb) * (double)(a->E - b->E);
+            const double e = exp(x), prob = e < 1.0 ? e : 1.0;
+            const double u = mt_double(&a->rng); /* always drawn, from the lower rung's stream */
+            if (prob < 1.0 && ulp_distance(u, prob) <= 4) a->ties++;
+            if (u < prob) {
+                const int ca = on_rung[t];
+                on_rung[t] = on_rung[t + 1], on_rung[t + 1] = ca;
+                a->rung = t + 1, b->rung = t;
+                a->n_exch++, b->n_exch++;
+            }
+        }
+    }
+    for (int c = 0; c < R; c++) {
+        if (rc == MCQ_OK) xchain_finish(&ch[c]);
+        xchain_free(&ch[c]);
+    }
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * fan-out: one task per chain, chain r seeded with seeds[r] (experiments.py:507-517)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -824,6 +1035,7 @@ static int run_chain(const job_t* jb, int64_t r) {
 }
 
 static int run_one(const job_t* jb, int64_t r) {
+    if (jb->p->exchange_every > 0) return run_exchange_group(jb, r); /* the task is a ladder */
     if (jb->p->n_sets > 1) { /* batched schedules: chain r follows sets[r / chains_per_set] */
         const mcq_schedule* sc = &jb->p->sets[r / jb->p->chains_per_set];
         mcq_params q = *jb->p;
@@ -837,13 +1049,15 @@ static int run_one(const job_t* jb, int64_t r) {
     return run_chain(jb, r);
 }
 
+static int64_t n_tasks(const mcq_params* p) { return p->exchange_every > 0 ? p->n_chains / p->exchange_replicas : p->n_chains; }
+
 static void* worker(void* arg) {
     pool_t* pl = (pool_t*)arg;
     for (;;) {
         pthread_mutex_lock(&pl->mu);
         int64_t r = pl->next++;
         pthread_mutex_unlock(&pl->mu);
-        if (r >= pl->jb->p->n_chains) break;
+        if (r >= n_tasks(pl->jb->p)) break;
         int rc = run_one(pl->jb, r);
         if (rc != MCQ_OK) {
             pthread_mutex_lock(&pl->mu);
@@ -885,10 +1099,21 @@ static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq
     if (out->accept_bits && p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
     if (p->trace == MCQ_TRACE_I32 && (!out->energy_hist || !out->accept_bits))
         return fail(MCQ_EINVAL, "trace requested without buffers");
+    if (p->exchange_every < 0) return fail(MCQ_EINVAL, "negative exchange_every");
+    if (p->exchange_every > 0) {
+        const int R = p->exchange_replicas;
+        if (R != 2 && R != 4 && R != 8 && R != 16) return fail(MCQ_EINVAL, "exchange_replicas must be 2, 4, 8 or 16");
+        if (!p->exchange_ladder) return fail(MCQ_EINVAL, "exchange_every > 0 without exchange_ladder");
+        if (p->n_chains % R != 0 || (p->n_sets > 1 && p->chains_per_set % R != 0))
+            return fail(MCQ_EINVAL, "n_chains (and chains_per_set) must be multiples of exchange_replicas");
+        if (p->mode == MCQ_MODE_BOARD && p->patience >= 0 && p->patience <= p->n_steps)
+            return fail(MCQ_EINVAL, "replica exchange needs early stopping off (early_stop_patience None)");
+        if (p->trace == MCQ_TRACE_REDUCED) return fail(MCQ_EINVAL, "replica exchange runs with trace none or i32");
+    }
 
     job_t jb = {p, seeds, out, fast};
     if (n_threads <= 1) {
-        for (int64_t r = 0; r < p->n_chains; r++) {
+        for (int64_t r = 0; r < n_tasks(p); r++) {
             int rc = run_one(&jb, r);
             if (rc != MCQ_OK) return fail(rc, "chain failed");
         }

@@ -130,10 +130,17 @@ def test_trace_none_matches_trace_i32():
 
 
 def test_default_lane_choice_never_changes_a_result():
-    """lanes_per_chain = 0 lets the library choose (4 for boards up to N = 12, 8 for a launch too small to fill the SIMDs at 4,
-    8 beyond and for full_3d): whatever it chooses equals every explicit choice."""
+    """lanes_per_chain = 0 lets the library choose (4 for boards up to N = 12, 8 beyond and for full_3d; 8 or 16 for a board
+    launch that leaves the device less than half full): whatever it chooses equals every explicit choice."""
     sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
-    for N, mode, n_chains in ((12, "board", 48), (12, "board", 20000), (8, "board", 100), (12, "full_3d", 40)):
+    import ctypes
+
+    L = mcq_amd._lib.lib()
+    simds = L.mcq_device_simds()
+    for N, n, want in ((12, 48, 16), (12, 4 * simds, 16), (12, 8 * simds, 8), (12, 16 * simds, 4), (24, 48, 8), (24, 16 * simds, 8), (17, 48, 16)):
+        p = abi.make_params(N, 10, "random", sp, n, mcmc_type="board")
+        assert L.mcq_effective_lanes(ctypes.byref(p)) == want, (N, n)
+    for N, mode, n_chains in ((12, "board", 48), (12, "board", 20000), (8, "board", 100), (12, "full_3d", 40), (24, "board", 48), (24, "board", 9000)):
         n_steps = 400 if n_chains > 1000 else 1500
         seeds = abi.seeds_for(31 + N, n_chains)
         ref, _ = mcq_amd._lib.run_host(abi.make_params(N, n_steps, "random", sp, n_chains, mcmc_type=mode, early_stop_patience=200), seeds)
