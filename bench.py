@@ -159,6 +159,13 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
     base_seed = 42
     p = abi.make_params(args.N, args.n_steps, "random", sp, args.chains, mcmc_type=args.mcmc_type,
                         early_stop_patience=args.patience, trace=trace, lanes_per_chain=args.lanes, rng=args.rng)
+    def with_exchange(q):  # replica exchange between the chains of a ladder: NOT a mode of the reference, evidence only
+        if args.exchange:
+            lo, hi = (float(x) for x in args.ladder.split(","))
+            abi.set_exchange(q, args.exchange, lo * (hi / lo) ** (np.arange(args.replicas) / (args.replicas - 1)))
+        return q
+
+    with_exchange(p)
     # chains are sharded by contiguous global index; the seed of a chain does not depend on the GPU count
     seeds = abi.seeds_for(base_seed + rank * args.chains, args.chains)
     run = mcq_amd._lib.DeviceRun(p, seeds, trace=trace, states=True)
@@ -184,7 +191,8 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
     algo_bytes = ALGO_BYTES_PER_MOVE * local_moves if trace is True else 0.0
     achieved = algo_bytes / (sweep_avg_ms * 1e-3) / 1e9
 
-    key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}" + ("" if args.rng == "mt19937" else f"_{args.rng}") + ("" if trace is True else "_notrace" if trace is False else "_reduced")
+    key = f"{args.mcmc_type}_N{args.N}_c{args.chains}_s{args.n_steps}" + ("" if args.rng == "mt19937" else f"_{args.rng}") + ("" if trace is True else "_notrace" if trace is False else "_reduced") \
+        + ("" if not args.exchange else f"_x{args.exchange}")
     pmc, why = measured_traffic(key)
     line = {
         "metric": METRIC,
@@ -205,7 +213,8 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
                         f"{sp.get('beta_start', sp.get('beta_const'))}->{sp.get('beta_end', '')} "
                         + ("" if args.patience is None else f"early_stop_patience={args.patience} ")
                         + f"n_runs={args.chains}/GPU n_steps={args.n_steps} trace={'i32' if trace is True else 'none' if trace is False else 'reduced'}"
-                        + ("" if args.rng == "mt19937" else f" rng={args.rng} (NOT the reference's stream)"),
+                        + ("" if args.rng == "mt19937" else f" rng={args.rng} (NOT the reference's stream)")
+                        + ("" if not args.exchange else f" replica exchange every {args.exchange} steps over {args.replicas} rungs, beta x {args.ladder} (NOT a mode of the reference)"),
             "chains_total": total_chains,
             "lanes_per_chain": mcq_amd._lib.effective_lanes(run.p),
             "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; one packed SUM all-reduce for the summary",
@@ -214,6 +223,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         "mean_best_energy": sm["mean_best"],
         "acceptance_rate": sm["acceptance_rate"],
         "kernel_ms": {"init": sum(init_ms) / len(init_ms), "sweep": sweep_avg_ms},
+        **({"exchanges_per_chain": float(run.t["n_exchanges"].double().mean().item())} if args.exchange else {}),
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
@@ -250,6 +260,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         ctrace = trace is True
         pc = abi.make_params(args.N, args.n_steps, "random", sp, n_cpu, mcmc_type=args.mcmc_type, trace=ctrace, rng=args.rng,
                              early_stop_patience=args.patience)
+        with_exchange(pc)
         t1 = time.perf_counter()
         cres = oracle.run(pc, seeds[:n_cpu], trace=ctrace, states=True, n_threads=threads)
         dt = time.perf_counter() - t1
@@ -264,6 +275,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
         n_fast = min(8 * n_cpu, args.chains)
         pf = abi.make_params(args.N, args.n_steps, "random", sp, n_fast, mcmc_type=args.mcmc_type, trace=False, rng=args.rng,
                              early_stop_patience=args.patience)
+        with_exchange(pf)
         t2 = time.perf_counter()
         fres = oracle.run(pf, seeds[:n_fast], trace=False, states=False, n_threads=threads, fast=True)
         dt_fast = time.perf_counter() - t2
@@ -369,6 +381,9 @@ def main():
     ap.add_argument("--no-trace", action="store_true", help="same as --trace none")
     ap.add_argument("--trace", default="i32", choices=["i32", "none", "reduced"],
                     help="c2 / c3: full int32 energy trace (the headline), no trace, or per-step sums accumulated on the device")
+    ap.add_argument("--exchange", type=int, default=0, help="c2 / c3: replica exchange every K steps (0 = off; NOT a mode of the reference)")
+    ap.add_argument("--replicas", type=int, default=16, help="rungs of a ladder (2, 4, 8, 16)")
+    ap.add_argument("--ladder", default="0.7,1.4", help="beta multipliers of the lowest and highest rung (geometric in between)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = every CPU this process may use)")

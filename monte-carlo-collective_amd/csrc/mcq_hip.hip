@@ -1605,7 +1605,18 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     const int pcl = __builtin_amdgcn_ds_bpermute((lb + (paired ? prt : rung) * G) * 4, on_rung);
                     const int pE = __builtin_amdgcn_ds_bpermute((lb + pcl * G) * 4, E);
                     // the lower chain draws random() from its stream, always (like the uniform of a step): two ready words
-                    while (wave_any(rng.gen - rng.pos < 2u)) upkeep();
+                    // (a chain that has run dry is topped up on the spot; the others are left alone: a block requested here could
+                    // land at the next step's upkeep with no step's words consumed in between, i.e. into a ring that is still full)
+                    while (wave_any(rng.gen - rng.pos < 2u)) {
+                        if (rng.gen - rng.pos < 2u) {
+                            if constexpr (PHILOX) {
+                                rng.generate();
+                            } else {
+                                if (!rng.pending) rng.issue();
+                                rng.complete();
+                            }
+                        }
+                    }
                     const uint32_t xw1 = ring[rng.pos & (RING - 1)], xw2 = ring[(rng.pos + 1u) & (RING - 1)];
                     int dec = 0;
                     if (lower && paired) {
@@ -1901,16 +1912,16 @@ int device_simds() {
 }
 
 // lanes of a wavefront per chain a launch runs with: the caller's choice, or the default for the board size -- except that a board
-// launch on its own that leaves the device less than half full (under two wavefronts per SIMD a wavefront is bound by its own
-// latency, and a step is shorter with more lanes: profiles/r03_lane_table.txt) is spread over twice, then four times as many
-// wavefronts while it stays there.  Boards from N = 20 stop at 8 lanes (16 take the run-time probe loop and are slower).
+// launch on its own that leaves SIMDs empty is spread over twice, then four times as many wavefronts while every wavefront
+// still gets a SIMD to itself (a lone wavefront is bound by its own latency, and a step is shorter with more lanes:
+// profiles/r03_lane_table.txt).  Boards from N = 20 stop at 8 lanes (16 take the run-time probe loop and are slower).
 // (A caller that runs several launches side by side knows better and says so: jobs.plan_lanes.)
 int effective_lanes(const mcq_params* p) {
     int G = p->lanes_per_chain;
     if (!G) {
         G = mcq_default_lanes_n(p->mode, p->N);
         if (p->mode == MCQ_MODE_BOARD) {
-            const long long room = 2LL * device_simds();
+            const long long room = device_simds();
             const int top = p->N >= 20 ? 8 : 16;
             while (G < top && (p->n_chains * (2 * G) + 63) / 64 <= room) G *= 2;
         }
