@@ -715,6 +715,12 @@ struct Stream {
 #elif defined(MCQ_EXP_NT_STORE)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store((u32x4){v[0], v[1], v[2], v[3]}, (u32x4*)sword(i0));
+#elif defined(MCQ_EXP_LAST_TOUCH)
+            // timing experiment (profiles/r03_last_touch.txt): records are 128-byte aligned in this build, so the block with gi & 16
+            // is the second half of its line -- after its write-back the line is dead for ~100 steps: a streaming store for that one
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            if (gi & 16) __builtin_nontemporal_store((u32x4){v[0], v[1], v[2], v[3]}, (u32x4*)sword(i0));
+            else *(uint4*)sword(i0) = make_uint4(v[0], v[1], v[2], v[3]);
 #else
             *(uint4*)sword(i0) = make_uint4(v[0], v[1], v[2], v[3]);
 #endif
@@ -1830,7 +1836,11 @@ int validate(const mcq_params* p) {
 }
 
 // 64-byte multiple: the sweep reads and writes the MT words of a record in aligned 64-byte blocks
+#if defined(MCQ_EXP_LAST_TOUCH) || defined(MCQ_EXP_REC128)  // timing experiment: 128-byte records, so that a block's half of its line is known from its index
+int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 31) & ~31; }
+#else
 int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 15) & ~15; }
+#endif
 
 size_t n_sets_of(const mcq_params* p) { return p->n_sets > 1 ? (size_t)p->n_sets : 1; }
 // one table per schedule set, tab_stride elements apart (a 256-byte multiple for either element size)
