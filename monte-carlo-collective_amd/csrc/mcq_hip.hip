@@ -960,7 +960,10 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // and for config 5's N = 24 (8 lanes, reduced trace).
 // EXCH: replica exchange between the chains of a ladder (mcq_params.exchange_every > 0; never with PATIENCE or REDUCED).
 template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false>
-__global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : 4) void mcq_sweep_kernel(KArgs a) {
+#ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
+#define MCQ_EXP_WAVES 4
+#endif
+__global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
     static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
     WAVE_T0;
     // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
