@@ -140,6 +140,7 @@ struct KArgs {
     unsigned long long* dbg;  // MCQ_STAMPS diagnostic build only: per-section cycle sums
     long long exch_every;     // replica exchange: period in steps (0: off)
     int exch_R;               // rungs of a ladder
+    int low_water;            // stream upkeep runs when some chain of the wavefront holds fewer ready words than this
     const double* exch_ladder;  // [exch_R] beta multipliers per rung (workspace)
 };
 
@@ -959,7 +960,8 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // (12 vector instructions of ~208 per step on the headline problem); instantiated for N = 12, the size of BASELINE configs 2 and 3,
 // and for config 5's N = 24 (8 lanes, reduced trace).
 // EXCH: replica exchange between the chains of a ladder (mcq_params.exchange_every > 0; never with PATIENCE or REDUCED).
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false>
+// CAND5: board, five candidates for new_k instead of three (N <= 5, where all three equal old_k too often).
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false>
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
 #endif
@@ -1121,10 +1123,14 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     const uint32_t room_limit = PHILOX ? 48u : MODE == MCQ_MODE_BOARD ? 53u : 54u;
     // (A/B on one box, 100 000 steps: board N = 12 low water 16 / 20 / 24 / 28 / 32 / 36 -> 140.3 / 137.1 / 137.4 / 138.3 / 137.9* / 140.5* ms,
     // N = 24 the same shape; full_3d 20 / 24 / 28 / 32 -> 408.9 / 374.8 / 369.8 / 373.9 ms.  * = another box, shipped 135.4 there.)
-#ifndef MCQ_LOW_WATER
-#define MCQ_LOW_WATER (MODE == MCQ_MODE_BOARD ? 24 : 28)
+    // Sizes whose randint(0, N) rejects many words (N / (mask + 1) < 0.6: N = 9, 17, 18, 19) look further ahead for their five
+    // accepted words and run into a short ring more often: their mark is 28 (lone wavefront, 20 000 steps: N = 9 13.4 -> 12.7 ms,
+    // N = 17 19.4 -> 18.1 ms, N = 18 18.1 -> 17.5 ms; every other size loses 1-2 % at 28: profiles/r03_low_water.txt).  A run-time scalar.
+#ifdef MCQ_LOW_WATER
+    const uint32_t LOW_WATER = MCQ_LOW_WATER;
+#else
+    const uint32_t LOW_WATER = (uint32_t)a.low_water;
 #endif
-    constexpr uint32_t LOW_WATER = MCQ_LOW_WATER;
 
     // replica exchange: the chain's rung, the float32 image of its beta multiplier, accepted swaps; wave-uniform countdown and parity
     int rung = EXCH ? grp % a.exch_R : 0, n_exch = 0;
@@ -1266,16 +1272,29 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
                 const uint32_t avail = rng.gen - rng.pos;  // ring slots [pos, pos + avail) hold words
                 // an empty mask gives position -1 (the attempt is not used then): the fetches below read ring[s - 1 ..], still the chain's own LDS
-                // the fifth accepted word must leave its two followers inside the view: positions 0..29 (none there: p5 = -1)
-                const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5 & 0x3fffffffu);
-                // ... and inside the generated words: p5 + 2 < avail (avail >= 5 when there is a fifth word).  As ONE unsigned compare,
-                // p5 < draw_limit: no fifth word (0xffffffff) fails it, and so does everything under MCQ_FLAG_SEQUENTIAL_DRAWS (limit 0)
-                const uint32_t draw_limit = (avail - 2u) & batch_mask;
+                const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5);
+                // The candidate that becomes new_k must leave its two followers (the uniform's words) inside the view -- positions
+                // 0..29 -- and inside the generated words: kp + 2 < avail.  As ONE unsigned compare, kp < draw_limit: a position that
+                // does not exist (-1 = 0xffffffff) fails it, and so does everything under MCQ_FLAG_SEQUENTIAL_DRAWS (limit 0).  (Flags
+                // exist for generated words only, so a real position is < avail and avail - 2 cannot have wrapped for it.)  The test is
+                // on the candidate that is TAKEN -- the first one, (N - 1) / N of the time -- not on the last one that might be: sizes
+                // whose randint rejects many words (N = 9, 17: 44 % rejected) found five accepted words inside a short ring far less
+                // often than three.
+                const uint32_t draw_limit = min(avail - 2u, 30u) & batch_mask;
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  The uniform's two words follow the
                 // candidate that becomes new_k: they are fetched once that is known (the step is bound by instruction issue, not by
                 // this round trip: fetching them behind all three candidates up front cost 6 selects and 2 LDS instructions more).
                 const uint32_t* rs = ring + s;
                 const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3], w4 = rs[p4], w5 = rs[p5];
+                // CAND5 (N <= 5): two more candidates.  All candidates equal old_k with probability 1 / N^3 per chain -- 4 % at N = 3,
+                // so in 45 % of the steps of a 16-chain wavefront some chain went word by word; with five it is 1 / N^5.
+                int p6 = -1, p7 = -1;
+                uint32_t w6 = 0, w7 = 0;
+                if constexpr (CAND5) {
+                    const uint32_t v6 = v5 & (v5 - 1), v7 = v6 & (v6 - 1);
+                    p6 = lowest_bit(v6), p7 = lowest_bit(v7);
+                    w6 = rs[p6], w7 = rs[p7];
+                }
                 // the stream upkeep runs while those reads are in flight; it appends behind the words of this view
                 if (upkeep_now) upkeep();
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN);
@@ -1284,15 +1303,25 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 old_k = hts[cell];
                 if constexpr (EARLY_PROBES) load_probes();
                 const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
-                pc = use3 ? c3 : use4 ? c4 : c5;
-                const int kp = use3 ? p3 : use4 ? p4 : p5;
+                int kp, p_last;
+                if constexpr (CAND5) {
+                    const int c6 = (int)(w6 & maskN), c7 = (int)(w7 & maskN);
+                    const bool use5 = c5 != old_k, use6 = c6 != old_k;
+                    pc = use3 ? c3 : use4 ? c4 : use5 ? c5 : use6 ? c6 : c7;
+                    kp = use3 ? p3 : use4 ? p4 : use5 ? p5 : use6 ? p6 : p7;
+                    p_last = p7;
+                } else {
+                    pc = use3 ? c3 : use4 ? c4 : c5;
+                    kp = use3 ? p3 : use4 ? p4 : p5;
+                    p_last = p5;
+                }
                 uw1 = rs[kp + 1], uw2 = rs[kp + 2];  // (an unused attempt reads some words of the chain's ring: kp >= -1)
-                // three candidates in a row equal to old_k (1/N^3): word by word instead
-                uint32_t fifth = pc != old_k ? (uint32_t)p5 : 0xffffffffu;
-                asm volatile("" : "+v"(fifth));  // (keeps it one compare: the compiler would take the select apart into mask logic again)
-                batched = fifth < draw_limit;
+                // every candidate equal to old_k (1/N^3): word by word instead
+                uint32_t taken = pc != old_k ? (uint32_t)kp : 0xffffffffu;
+                asm volatile("" : "+v"(taken));  // (keeps it one compare: the compiler would take the select apart into mask logic again)
+                batched = taken < draw_limit;
                 rng.consume(batched ? (uint32_t)kp + 3u : 0u);
-                redraw_from = (uint32_t)p5 < draw_limit ? p5 + 1 : -1;  // (dead outside the rare path below)
+                redraw_from = (uint32_t)p_last < draw_limit ? p_last + 1 : -1;  // (dead outside the rare path below)
             } else {
                 // q = first word accepted for randint(0, Q); then a candidate (i, j, k) triple from the words accepted for
                 // randint(0, N) after it, and a second triple when the first cell is occupied; the uniform's two words follow the
@@ -1906,6 +1935,7 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->tab_stride = (long long)tab_stride_for(p);
     a->red_set_stride = (long long)(red_set_bytes(p) / 8);
     a->pace = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p));
+    a->low_water = p->mode == MCQ_MODE_BOARD ? ((double)p->N / (double)(a->maskN + 1u) < 0.6 ? 28 : 24) : 28;
     a->exch_every = p->exchange_every, a->exch_R = p->exchange_every > 0 ? p->exchange_replicas : 1;
     a->exch_ladder = (const double*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES);
     a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES);
@@ -1944,7 +1974,7 @@ int effective_lanes(const mcq_params* p) {
     return G;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -1954,9 +1984,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -2048,6 +2078,8 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 case 3: return a.N == 12 ? launch_sweep<MODE, G, true, 3, false, false, 12>(a, s) : launch_sweep<MODE, G, true, 3, false>(a, s);
                 default: break;
                 }
+            if (!pat && !a.red && a.N <= 5)  // five candidates for new_k: the small cells of measure_min_energy_vs_N (BASELINE config 4)
+                return a.N <= 4 ? launch_sweep<MODE, G, false, 1, false, false, 0, false, true>(a, s) : launch_sweep<MODE, G, false, 2, false, false, 0, false, true>(a, s);
             if (!pat && a.N == 12)  // the size of BASELINE config 2: N as a compile-time constant
                 return a.red ? launch_sweep<MODE, G, false, 3, true, false, 12>(a, s) : launch_sweep<MODE, G, false, 3, false, false, 12>(a, s);
             if (!pat) switch ((a.N + G - 1) / G) {
