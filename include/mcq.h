@@ -177,7 +177,7 @@ int mcq_device_count(void);
 
 /* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 12 and 8 beyond, full_3d 8
  * (mcq_default_lanes: the value for small boards).  A board launch that leaves SIMDs empty runs at twice or four times the
- * lanes while every wavefront still has a SIMD to itself (N >= 20: at most 8); with replica exchange a ladder must fit one
+ * lanes while every wavefront still has a SIMD to itself (N >= 20: at most 8; N <= 8: always 4); with replica exchange a ladder must fit one
  * wavefront.  mcq_effective_lanes tells.  The lane count never changes a result. */
 int32_t mcq_default_lanes(int32_t mode);
 int32_t mcq_default_lanes_n(int32_t mode, int32_t N);

@@ -95,10 +95,12 @@ namespace {
         if (threadIdx.x == 0)                                                 \
             for (int k_ = 0; k_ < 8; k_++) atomicAdd(&(dbg)[k_], st_acc[k_]); \
     } while (0)
+#define STAMP_COUNT(k) (st_acc[k] += 1)
 #else
 #define STAMP_DECL
 #define STAMP(k)
 #define STAMP_FLUSH(dbg)
+#define STAMP_COUNT(k)
 #endif
 
 constexpr int MT_N = 624;
@@ -1181,7 +1183,9 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             uint32_t oldp = 0;
             uint32_t uw1 = 0, uw2 = 0;   // the two words of random()
             int stage_no = 0;
-            int redraw_from = -1;        // board: words to skip when only new_k has to be drawn again
+            int redraw_from = -1;        // board: words to skip when the word-by-word draw can go on from what the batched attempt established
+            uint32_t seen = 0;           // full_3d: what the batched attempt established (bit 0: the first triple's words are all there, ...)
+            int third_end = 0;           // full_3d: words up to and including the first triple
             // stream upkeep runs for every chain of the wavefront together (cadence: see LOW_WATER above)
             auto upkeep = [&]() {
                 STAMP(0);
@@ -1268,19 +1272,21 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // height, and the uniform's two words behind the chosen candidate.  Where the attempt is not valid the
                 // fetched values are simply not used (every address is inside the chain's LDS slice).
                 const uint32_t s = rng.pos & (RING - 1);
+                // (positions 0..29 from the second word on -- the mask rides in the three-input AND: whichever candidate is taken, its
+                // two followers are inside the view; a first word at 30 / 31 leaves no second one and the attempt is not used)
                 const uint32_t v1 = (uint32_t)rng.ok;
-                const uint32_t v2 = v1 & (v1 - 1), v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
+                const uint32_t v2 = v1 & (v1 - 1) & 0x3fffffffu, v3 = v2 & (v2 - 1), v4 = v3 & (v3 - 1), v5 = v4 & (v4 - 1);
                 const uint32_t avail = rng.gen - rng.pos;  // ring slots [pos, pos + avail) hold words
                 // an empty mask gives position -1 (the attempt is not used then): the fetches below read ring[s - 1 ..], still the chain's own LDS
                 const int p1 = lowest_bit(v1), p2 = lowest_bit(v2), p3 = lowest_bit(v3), p4 = lowest_bit(v4), p5 = lowest_bit(v5);
-                // The candidate that becomes new_k must leave its two followers (the uniform's words) inside the view -- positions
-                // 0..29 -- and inside the generated words: kp + 2 < avail.  As ONE unsigned compare, kp < draw_limit: a position that
+                // The candidate that becomes new_k must leave its two followers (the uniform's words) inside the generated words:
+                // kp + 2 < avail.  As ONE unsigned compare, kp < draw_limit: a position that
                 // does not exist (-1 = 0xffffffff) fails it, and so does everything under MCQ_FLAG_SEQUENTIAL_DRAWS (limit 0).  (Flags
                 // exist for generated words only, so a real position is < avail and avail - 2 cannot have wrapped for it.)  The test is
                 // on the candidate that is TAKEN -- the first one, (N - 1) / N of the time -- not on the last one that might be: sizes
                 // whose randint rejects many words (N = 9, 17: 44 % rejected) found five accepted words inside a short ring far less
                 // often than three.
-                const uint32_t draw_limit = min(avail - 2u, 30u) & batch_mask;
+                const uint32_t draw_limit = (avail - 2u) & batch_mask;
                 // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring.  The uniform's two words follow the
                 // candidate that becomes new_k: they are fetched once that is known (the step is bound by instruction issue, not by
                 // this round trip: fetching them behind all three candidates up front cost 6 selects and 2 LDS instructions more).
@@ -1359,14 +1365,23 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     const uint32_t w4 = rs[p4], w5 = rs[p5], w6 = rs[p6];
                     const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
                     const uint32_t cw2 = colw[__mul24(i2, N) + j2];
-                    const bool second = !batched && !free1 && !((cw2 >> k2) & 1u) && (uint32_t)p6 < draw_limit;
-                    pa = second ? i2 : pa, pb = second ? j2 : pb, pc = second ? k2 : pc, pu = second ? p6 : pu;
+                    // (a position counts only when its word has been generated; nothing does under MCQ_FLAG_SEQUENTIAL_DRAWS)
+                    const uint32_t availm = avail & batch_mask;
+                    const bool valid3 = (uint32_t)p3 < availm, valid6 = (uint32_t)p6 < availm, taken2 = ((cw2 >> k2) & 1u) != 0;
+                    const bool use2 = !batched && !free1 && valid6 && !taken2;  // the second triple's cell is the new cell
+                    const bool second = use2 && (uint32_t)p6 < draw_limit;      // ... and its uniform's words are there
+                    pa = use2 ? i2 : pa, pb = use2 ? j2 : pb, pc = use2 ? k2 : pc, pu = second ? p6 : pu;
                     batched = batched || second;
+                    // (what the word-by-word path needs to know should it be taken: see below)
+                    seen = (valid3 ? 1u : 0u) | (valid6 ? 2u : 0u) | (free1 ? 4u : 0u) | (taken2 ? 8u : 0u) | ((uint32_t)(p6 + 1) << 4);
                 }
+                third_end = p3 + 1;
                 uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
                 rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
+            STAMP_COUNT(7);  // (diagnostic build: wavefront-steps, and those of them that take the word-by-word path)
             if (__builtin_expect(wave_any(!batched), 0)) {  // wave-uniform guard of the rare path
+                STAMP_COUNT(6);
                 if (!batched) {
                     if constexpr (MODE == MCQ_MODE_BOARD) {
                         // Three candidates in a row equal to old_k, all of them inside the generated words (1/N^3 per chain: 4 % at
@@ -1376,6 +1391,13 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                             rng.consume((uint32_t)redraw_from);
                             stage_no = 2;
                         }
+                    } else if (seen & 1u) {
+                        // Both cells taken (Q^2 / N^6 per chain: 5.5 % of the steps of an 8-chain wavefront at N = 12), or the ring
+                        // short: q and the triples whose words are all there stand.  The draw goes on behind the last of them --
+                        // with a new triple (stage 1) or, its cell being free, only the uniform (stage 4) -- instead of starting over.
+                        const bool valid6 = (seen & 2u) != 0, free1 = (seen & 4u) != 0, taken2 = (seen & 8u) != 0;
+                        rng.consume((uint32_t)((free1 || !valid6) ? third_end : (int)(seen >> 4)));
+                        stage_no = (free1 || (valid6 && !taken2)) ? 4 : 1;
                     }
                     sequential();
                     if constexpr (EARLY_PROBES) load_probes();
@@ -1957,7 +1979,8 @@ int device_simds() {
 // lanes of a wavefront per chain a launch runs with: the caller's choice, or the default for the board size -- except that a board
 // launch on its own that leaves SIMDs empty is spread over twice, then four times as many wavefronts while every wavefront
 // still gets a SIMD to itself (a lone wavefront is bound by its own latency, and a step is shorter with more lanes:
-// profiles/r03_lane_table.txt).  Boards from N = 20 stop at 8 lanes (16 take the run-time probe loop and are slower).
+// profiles/r03_lane_table.txt).  Boards from N = 20 stop at 8 lanes (16 take the run-time probe loop and are slower); boards up
+// to N = 8 stay at 4 (one probe pass or two: more lanes shorten nothing, and the 4-lane kernels are the specialised ones).
 // (A caller that runs several launches side by side knows better and says so: jobs.plan_lanes.)
 int effective_lanes(const mcq_params* p) {
     int G = p->lanes_per_chain;
@@ -1965,7 +1988,7 @@ int effective_lanes(const mcq_params* p) {
         G = mcq_default_lanes_n(p->mode, p->N);
         if (p->mode == MCQ_MODE_BOARD) {
             const long long room = device_simds();
-            const int top = p->N >= 20 ? 8 : 16;
+            const int top = p->N <= 8 ? 4 : p->N >= 20 ? 8 : 16;
             while (G < top && (p->n_chains * (2 * G) + 63) / 64 <= room) G *= 2;
         }
         // replica exchange: a ladder lives in one wavefront (its chains swap through cross-lane moves, no barrier)
@@ -2284,6 +2307,7 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, g_dbg, 64, hipMemcpyDeviceToHost));
         const char* names[8] = {"loop", "stream_upkeep", "draws", "dE", "accept", "apply+history", "-", "-"};
+        fprintf(stderr, "STAMP word-by-word draws: %llu of %llu wavefront-steps (%.3f %%)\n", h[6], h[7], 100.0 * h[6] / (h[7] ? h[7] : 1));
         unsigned long long tot = 0;
         for (int k = 0; k < 6; k++) tot += h[k];
         for (int k = 0; k < 6; k++) fprintf(stderr, "STAMP %-14s %14llu  %5.1f %%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));

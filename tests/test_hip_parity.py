@@ -137,7 +137,7 @@ def test_default_lane_choice_never_changes_a_result():
 
     L = mcq_amd._lib.lib()
     simds = L.mcq_device_simds()
-    for N, n, want in ((12, 48, 16), (12, 4 * simds, 16), (12, 8 * simds, 8), (12, 16 * simds, 4), (24, 48, 8), (24, 16 * simds, 8), (17, 48, 16)):
+    for N, n, want in ((12, 48, 16), (12, 4 * simds, 16), (12, 8 * simds, 8), (12, 16 * simds, 4), (24, 48, 8), (24, 16 * simds, 8), (17, 48, 16), (8, 48, 4), (3, 48, 4)):
         p = abi.make_params(N, 10, "random", sp, n, mcmc_type="board")
         assert L.mcq_effective_lanes(ctypes.byref(p)) == want, (N, n)
     for N, mode, n_chains in ((12, "board", 48), (12, "board", 20000), (8, "board", 100), (12, "full_3d", 40), (24, "board", 48), (24, "board", 9000)):
