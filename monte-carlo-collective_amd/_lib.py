@@ -6,6 +6,8 @@ calls raise.  (The CPU oracle under oracle/ is test infrastructure and is never 
 import ctypes as C
 import importlib.util
 import os
+import sys
+import warnings
 
 import numpy as np
 
@@ -18,7 +20,16 @@ _lib = None
 # default, the 18 launches of measure_min_energy_vs_N at 3 x 1 024 chains each run at a third of the rate they reach with 16
 # queues (profiles/r02_small_launches.txt).  The variable is read when the HIP runtime initialises, so it is set here, at
 # import, unless the user has chosen a value; it does not affect single-stream runs.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = "24"
+    # The HIP runtime reads the variable when it initialises.  A process that touched the GPU before importing this package
+    # keeps the runtime's default of 4 queues: say so instead of silently running the drivers' job lists at a third of their
+    # rate.  (Entry points that own the process -- bench.py, `python -m mcq_amd.drivers` -- import this before torch.)
+    _torch = sys.modules.get("torch")
+    if _torch is not None and _torch.cuda.is_initialized():
+        warnings.warn("mcq_amd: the GPU runtime was initialised before this import, so GPU_MAX_HW_QUEUES=24 cannot take effect; "
+                      "job lists of many small launches (drivers.measure_min_energy_vs_N) will share 4 hardware queues. "
+                      "Import mcq_amd first or export GPU_MAX_HW_QUEUES yourself.", RuntimeWarning, stacklevel=2)
 
 
 class McqError(RuntimeError):

@@ -81,7 +81,7 @@ namespace {
 #endif
 
 #ifdef MCQ_STAMPS
-#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k)                                                        \
     do {                                                                \
         __builtin_amdgcn_sched_barrier(0);                              \
@@ -93,7 +93,7 @@ namespace {
 #define STAMP_FLUSH(dbg)                                                      \
     do {                                                                      \
         if (threadIdx.x == 0)                                                 \
-            for (int k_ = 0; k_ < 8; k_++) atomicAdd(&(dbg)[k_], st_acc[k_]); \
+            for (int k_ = 0; k_ < 12; k_++) atomicAdd(&(dbg)[k_], st_acc[k_]); \
     } while (0)
 #define STAMP_COUNT(k) (st_acc[k] += 1)
 #else
@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     uint32_t accw = 0;  // accept bits of the current block of 32 steps
     const bool exact_only = (a.flags & MCQ_FLAG_EXACT_EXP) != 0;
     // half-width of the float32 bracket around exp(x) 2^27 as w = e27 * w_scale + w_bias; MCQ_FLAG_EXACT_EXP makes it cover everything
-    uint32_t w_scale_bits = exact_only ? 0u : 0x3a800000u /* 2^-10 */, w_bias_bits = exact_only ? 0x7f61b1e6u /* 3.0e38 */ : 0x3f000000u /* 0.5 */;
+#ifndef MCQ_W_SCALE_BITS
+#define MCQ_W_SCALE_BITS 0x3a800000u /* 2^-10 */
+#endif
+    uint32_t w_scale_bits = exact_only ? 0u : MCQ_W_SCALE_BITS, w_bias_bits = exact_only ? 0x7f61b1e6u /* 3.0e38 */ : 0x3f000000u /* 0.5 */;
     asm volatile("" : "+s"(w_scale_bits), "+s"(w_bias_bits));  // two scalars, no select per step
     const float w_scale = __uint_as_float(w_scale_bits), w_bias = __uint_as_float(w_bias_bits);
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
@@ -1360,6 +1363,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 // wavefront, so in every second step of 8 chains -- is the second triple looked at (it was fetched up front before:
                 // ~30 instructions per step; the step is bound by instruction issue, not by this extra round trip).
                 if (wave_any(!batched)) {
+                    STAMP_COUNT(10);
                     const uint32_t n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                     const int p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6 & 0x3fffffffu);
                     const uint32_t w4 = rs[p4], w5 = rs[p5], w6 = rs[p6];
@@ -1554,6 +1558,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             bool exact = __builtin_fabsf(d) <= (xneg ? w : -1.0f);
             uint32_t acc = (xneg ? d : -1.0f) < 0.0f ? 1u : 0u;  // 0 / 1 in a vector register: the rare branch below may rewrite it
             if (__builtin_expect(wave_any(exact), 0)) {  // ~0.1 % of the steps of a chain
+                STAMP_COUNT(8);
                 if (exact) {
                     const int r = accept_exact(EXCH ? beta_tab[step] * a.exch_ladder[rung] : beta_tab[step], dE, uw1, uw2);
                     acc = (uint32_t)r & 1u;
@@ -1581,6 +1586,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             best = min(best, E);
             const int e = step + 1;
             if (__builtin_expect(wave_any(improved), 0)) {  // rare after the first few hundred steps
+                STAMP_COUNT(9);
                 if (improved) {
                     // first index of the minimum of energy_history (experiments.py:364-365); with patience 0 the chain stops
                     // right here without appending this entry (no_improvement_steps = 0 >= 0), so the index stays
@@ -2292,8 +2298,8 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     hipEvent_t* ev = evs.ev;
     for (int t = 0; t < 3; t++) HIP_TRY(hipEventCreate(&ev[t]));
 #ifdef MCQ_STAMPS
-    if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 64));
-    HIP_TRY(hipMemset(g_dbg, 0, 64));
+    if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 96));
+    HIP_TRY(hipMemset(g_dbg, 0, 96));
 #endif
 #ifdef MCQ_WAVE_TIMES
     const size_t wt_waves = 1 << 16;
@@ -2303,11 +2309,13 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
     int rc = run_device_impl(p, seeds, out, workspace, workspace_bytes, hip_stream, ev, p ? p->beta_table : nullptr);
 #ifdef MCQ_STAMPS
     if (rc == MCQ_OK) {
-        unsigned long long h[8];
+        unsigned long long h[12];
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(h, g_dbg, 64, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h, g_dbg, 96, hipMemcpyDeviceToHost));
         const char* names[8] = {"loop", "stream_upkeep", "draws", "dE", "accept", "apply+history", "-", "-"};
         fprintf(stderr, "STAMP word-by-word draws: %llu of %llu wavefront-steps (%.3f %%)\n", h[6], h[7], 100.0 * h[6] / (h[7] ? h[7] : 1));
+        fprintf(stderr, "STAMP float64 accept path %.3f %%, improvement path %.3f %%, second triple (full_3d) %.3f %% of the wavefront-steps\n",
+                100.0 * h[8] / (h[7] ? h[7] : 1), 100.0 * h[9] / (h[7] ? h[7] : 1), 100.0 * h[10] / (h[7] ? h[7] : 1));
         unsigned long long tot = 0;
         for (int k = 0; k < 6; k++) tot += h[k];
         for (int k = 0; k < 6; k++) fprintf(stderr, "STAMP %-14s %14llu  %5.1f %%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));

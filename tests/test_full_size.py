@@ -9,6 +9,8 @@
 
 Everything stays on the device (the 26 GB trace never crosses PCIe); the checks run in chunks of chains.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -156,10 +158,11 @@ def test_config4_size_cells():
     (that driver discards histories): every chain's best / final state recounted pair by pair, both ends of every cell
     against the oracle; known answers: klarner boards with gcd(N, 210) == 1 start at energy 0 (mcmc_board.py:21)."""
     sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    n_steps = int(os.environ.get("MCQ_C4_STEPS", "100000"))  # SURVEY 8d also names 10^6 (MCQ_C4_STEPS=1000000: run once per round, profiles/)
     for init in ("random", "latin", "klarner"):
         off = sum(ord(c) for c in init) % 1000
         for idx, N in enumerate(range(3, 21)):
-            mn = _check_run("board", N, 100000, 8192, sp, n_sample=2, init=init, base_seed=42 + 10 * idx + off, trace=False)
+            mn = _check_run("board", N, n_steps, 8192, sp, n_sample=2, init=init, base_seed=42 + 10 * idx + off, trace=False)
             if init == "klarner" and N in (11, 13, 17, 19):
                 assert mn == 0
 
