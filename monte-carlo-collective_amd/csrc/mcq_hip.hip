@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     //   vam     bit (i + j) set iff the anti-diagonal probe (m, i + j - m) is
     constexpr bool PACKED = (MODE == MCQ_MODE_BOARD && NT >= 1 && NT * G <= 16) || NARROW;  // N <= 16
     constexpr int PG = NARROW ? G / 2 : G;  // lanes that share one set of probes
-    constexpr int NTP = PACKED ? NT : 1;
+    constexpr bool UNROLLED = PACKED || (MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 4);  // probe passes with per-lane constants (boards beyond N = 16: pm and krc only; five or six passes would spill)
+    constexpr int NTP = UNROLLED ? NT : 1;
     int pm[NTP];
     uint32_t krc[NTP], vdm[NTP], vam[NTP];
 #pragma unroll
@@ -1251,11 +1252,15 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
 
             // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
             // the old height (with four, the 16 extra live registers would spill)
-#ifdef MCQ_EXP_EARLY_RED
-            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3;
-#else
-            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && PACKED && NT <= 3 && !REDUCED;
+            // (Boards beyond N = 16 at 8 lanes -- three unpacked passes -- can do the same, MCQ_EARLY_UNPACKED=1: their twelve byte
+            // reads sit behind the rare-path branch, one LDS round trip later than they have to.  A wavefront alone on its SIMD gains
+            // 7.5 % (N = 24: 14.14 -> 13.08 ms per 20 000 steps), a full device LOSES 3.5 % (config 5 at 8 192 chains per pair: 556 ->
+            // 578 ms; twelve more live registers across the draw) and two wavefronts per SIMD are level: off.  With the reduced trace
+            // the packed variants request early too since round 3: +0.9 % at N = 12.  profiles/r03_early_probes.txt)
+#ifndef MCQ_EARLY_UNPACKED
+#define MCQ_EARLY_UNPACKED 0
 #endif
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 3 && (PACKED || MCQ_EARLY_UNPACKED != 0);
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);
@@ -1427,9 +1432,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                 const uint8_t* ha = hj + i;
                 const int dji = j - i, sij = i + j;
                 int acc = 0;
-                auto probe = [&](int m, bool in_board) {
-                    const int mN_ = __mul24(m, N);
-                    const uint32_t hr = hrow[m], hc = hj[mN_], hdg = hd[mN_ + m], han = ha[mN_ - m];
+                auto probe = [&](int m, bool in_board, uint32_t hr, uint32_t hc, uint32_t hdg, uint32_t han) {
                     const uint32_t dr = abs_diff(m, j), dc = abs_diff(m, i);
                     const uint32_t Mor = Bo | (Bo << dr) | (Bo >> dr), Mnr = Bn | (Bn << dr) | (Bn >> dr);
                     const uint32_t Moc = Bo | (Bo << dc) | (Bo >> dc), Mnc = Bn | (Bn << dc) | (Bn >> dc);
@@ -1465,12 +1468,22 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     const uint32_t both = (uint32_t)group_sum<G>((int)accp);  // at most 4 * N hits per half: no carry
                     dE = (int)(both >> 16) - (int)(both & 0xffffu) + 4;
                 } else {
-                    if constexpr (NT > 0) {
+                    if constexpr (UNROLLED) {  // the heights were requested by load_probes (a clamped probe reads cell N - 1 and is discarded)
+                        if constexpr (!EARLY_PROBES) load_probes();
 #pragma unroll
-                        for (int t = 0; t < NT; t++) probe(gl + t * G, t + 1 < NT || gl + t * G < N);
+                        for (int t = 0; t < NT; t++) probe(pm[t], t + 1 < NT || krc[t] != 0u, ph[4 * t], ph[4 * t + 1], ph[4 * t + 2], ph[4 * t + 3]);
+                    } else if constexpr (NT > 0) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++) {
+                            const int m = gl + t * G, mN_ = __mul24(m, N);
+                            probe(m, t + 1 < NT || m < N, hrow[m], hj[mN_], hd[mN_ + m], ha[mN_ - m]);
+                        }
                     } else {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                        for (int m = gl; m < N; m += G) probe(m, true);
+                        for (int m = gl; m < N; m += G) {
+                            const int mN_ = __mul24(m, N);
+                            probe(m, true, hrow[m], hj[mN_], hd[mN_ + m], ha[mN_ - m]);
+                        }
                     }
                     dE = group_sum<G>(acc) + 4;
                 }
