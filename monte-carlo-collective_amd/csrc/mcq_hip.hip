@@ -1260,7 +1260,11 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
 #ifndef MCQ_EARLY_UNPACKED
 #define MCQ_EARLY_UNPACKED 0
 #endif
+#ifdef MCQ_EXP_NO_EARLY  // timing experiment: no early requests at all
+            constexpr bool EARLY_PROBES = false;
+#else
             constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 3 && (PACKED || MCQ_EARLY_UNPACKED != 0);
+#endif
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
                 const uint8_t* hrow = hts + __mul24(pa, N);

@@ -15,19 +15,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    r = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    r = sys.argv[1] if len(sys.argv) > 1 else "r03"
     ev = os.path.join(ROOT, "gpurun_out", f"{r}_evidence")
     prof = os.path.join(ROOT, "profiles")
     run = lambda *a: subprocess.run([sys.executable] + list(a), check=True, cwd=ROOT, capture_output=True, text=True).stdout
     for src, key, out in (("pmc_headline", "board_N12_c65536_s100000", f"profiles/{r}_pmc_summary.json"),
                           ("pmc_c3", "full_3d_N12_c65536_s100000", f"profiles/{r}_pmc_summary_full3d.json"),
-                          ("pmc_philox", "board_N12_c65536_s100000_philox", f"profiles/{r}_pmc_summary_philox.json")):
+                          ("pmc_philox", "board_N12_c65536_s100000_philox", f"profiles/{r}_pmc_summary_philox.json"),
+                          ("pmc_n24", "board_N24_c65536_s100000_reduced", f"profiles/{r}_pmc_summary_n24.json")):
         if os.path.exists(os.path.join(ev, src, "summary.json")):
             run("tools/pmc_refresh.py", os.path.join("gpurun_out", f"{r}_evidence", src), key, out)
             print("refreshed", key)
     copies = {"bench.json": f"{r}_bench.json", "configs.jsonl": f"{r}_configs.jsonl", "patience.txt": f"{r}_patience.txt",
               "occupancy_board.txt": f"{r}_occupancy_board.txt", "occupancy_full3d.txt": f"{r}_occupancy_full3d.txt",
-              "stamps.txt": f"{r}_stamp_shares.txt", "small_launches.txt": f"{r}_small_launches.txt", "c5_rss.txt": f"{r}_c5_host_memory.txt",
+              "stamps.txt": f"{r}_stamp_shares.txt", "occupancy_n24.txt": f"{r}_occupancy_n24.txt", "c4_1e6.json": f"{r}_c4_1e6_steps.json", "small_launches.txt": f"{r}_small_launches.txt", "c5_rss.txt": f"{r}_c5_host_memory.txt",
               "lds_stride_ab.txt": f"{r}_lds_stride_ab.txt", "lds_stride_pmc.txt": f"{r}_lds_stride_pmc.txt",
               "kernel_stats_bench.json": f"{r}_kernel_stats_bench.json"}
     for a, b in copies.items():
