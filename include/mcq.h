@@ -134,12 +134,14 @@ typedef struct mcq_params {
      * trace != REDUCED. */
     int64_t exchange_every;        /* 0 = off */
     int32_t exchange_replicas;     /* R */
-    int32_t reserved0;
+    int32_t n_queens;              /* full_3d only: Q queens instead of N*N (State3DQueens(N, Q=...), mcmc.py:6-18; metropolis_mcmc(..., Q=...),
+                                      experiments.py:199-203), 2 <= Q < N^3, random init only (latin / klarner assume Q = N^2: mcmc.py:21-25);
+                                      0 = N*N.  state_bytes becomes 3 Q (mcq_state_bytes_for). */
     const double* exchange_ladder; /* HOST pointer (also for mcq_run_device), R multipliers */
 } mcq_params;
 
 /*
- * Per-chain outputs; every array is caller-allocated.  state_bytes = mcq_state_bytes(N, mode):
+ * Per-chain outputs; every array is caller-allocated.  state_bytes = mcq_state_bytes(N, mode) (mcq_state_bytes_for(p) with n_queens):
  *   board:   N*N uint8 heights, row-major heights[i][j]        (mcmc_board.py:28)
  *   full_3d: Q*3 uint8 (i, j, k) per queen, in queen-index order (mcmc.py:101)
  * Pointers that may be NULL are marked optional.
@@ -187,8 +189,10 @@ int32_t mcq_effective_lanes(const mcq_params* p);
 /* SIMDs of the current device (4 per compute unit; 1024 when no device answers): what the small-launch rule compares with */
 int32_t mcq_device_simds(void);
 
-/* bytes of one chain's state record in best_state / final_state; 0 on bad arguments */
+/* bytes of one chain's state record in best_state / final_state; 0 on bad arguments.  mcq_state_bytes: Q = N*N queens;
+ * mcq_state_bytes_for: the parameter block's own count (n_queens). */
 size_t mcq_state_bytes(int32_t N, int32_t mode);
+size_t mcq_state_bytes_for(const mcq_params* p);
 
 /* bytes of device scratch mcq_run_device needs for these parameters; 0 on bad arguments */
 size_t mcq_workspace_bytes(const mcq_params* p);

@@ -96,6 +96,8 @@ def lib():
         L.mcq_device_simds.restype = C.c_int32
         L.mcq_state_bytes.restype = C.c_size_t
         L.mcq_state_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.mcq_state_bytes_for.restype = C.c_size_t
+        L.mcq_state_bytes_for.argtypes = [C.POINTER(abi.Params)]
         L.mcq_workspace_bytes.restype = C.c_size_t
         L.mcq_workspace_bytes.argtypes = [C.POINTER(abi.Params)]
         L.mcq_run_device.restype = C.c_int

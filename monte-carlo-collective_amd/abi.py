@@ -69,7 +69,7 @@ class Params(C.Structure):
         ("beta_table", C.c_void_p),
         ("exchange_every", C.c_int64),
         ("exchange_replicas", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("n_queens", C.c_int32),
         ("exchange_ladder", C.POINTER(C.c_double)),
     ]
 
@@ -120,9 +120,9 @@ OUTPUT_DTYPES = {
 }
 
 
-def state_bytes(N, mode):
-    """Bytes of one chain's state record: N*N heights (board) or Q*3 coordinates (full_3d)."""
-    return N * N if mode == MODE_BOARD else 3 * N * N
+def state_bytes(N, mode, n_queens=0):
+    """Bytes of one chain's state record: N*N heights (board) or Q*3 coordinates (full_3d; Q = N*N unless n_queens names a count)."""
+    return N * N if mode == MODE_BOARD else 3 * (n_queens if n_queens else N * N)
 
 
 def hist_stride_for(n_steps):
@@ -147,7 +147,7 @@ def output_shapes(p, trace=True, states=True):
         shapes["energy_hist"] = (n, p.hist_stride)
         shapes["accept_bits"] = (n, p.bits_stride)
     if states:
-        sb = state_bytes(p.N, p.mode)
+        sb = state_bytes(p.N, p.mode, p.n_queens)
         shapes["best_state"] = (n, sb)
         shapes["final_state"] = (n, sb)
     if p.exchange_every > 0:
@@ -226,7 +226,7 @@ def make_params_sets(N, n_steps, init_mode, schedule_sets, chains_per_set, mcmc_
 
 
 def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="full_3d", early_stop_patience=None,
-                trace=True, flags=0, lanes_per_chain=0, device=-1, rng="mt19937"):
+                trace=True, flags=0, lanes_per_chain=0, device=-1, rng="mt19937", Q=None):
     """Build a Params from the reference's vocabulary.  Raises ValueError exactly where the
     reference does: unknown schedule type (experiments.py:105), missing beta parameters
     (experiments.py:85-102), unknown init_mode (mcmc_board.py:59, mcmc.py:104)."""
@@ -273,6 +273,17 @@ def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="ful
     p.lanes_per_chain = lanes_per_chain
     p.device = device
     p._schedules = [dict(schedule_params)]  # what abi.beta_table evaluates (the struct itself only holds enums and doubles)
+    if Q is not None and int(Q) != N * N:  # State3DQueens(N, Q=...): mcmc.py:6-18
+        Q = int(Q)
+        if p.mode != MODE_FULL3D:
+            raise ValueError("Q applies to mcmc_type full_3d (a board has one queen per column)")
+        if init_mode in ("latin", "klarner"):
+            raise ValueError(f"{init_mode} initialization assumes Q = N^2, got Q={Q}, N^2={N * N}.")  # mcmc.py:21-25
+        if Q > N ** 3:
+            raise ValueError(f"Q={Q} cannot exceed N^3={N ** 3}.")  # mcmc.py:94-95
+        if Q < 2 or Q == N ** 3 or Q > 32767:
+            raise ValueError(f"this build runs 2 <= Q < N^3 and Q <= 32767 queens, got Q={Q}")
+        p.n_queens = Q
     return p
 
 

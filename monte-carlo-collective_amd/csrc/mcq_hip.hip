@@ -118,7 +118,8 @@ constexpr int REC_E0 = 627;       // record word: initial energy
 constexpr int REC_STATE = 628;    // first word of the state bytes (heights or (i,j,k) triplets)
 
 struct KArgs {
-    int N, Q, mode, init, sched, rng;
+    int N, Q, mode, init, sched, rng;  // Q queens: N * N, or mcq_params.n_queens (full_3d, random init)
+    int NN;                 // N * N: columns of the board
     unsigned flags;
     unsigned maskN, maskQ;  // smallest 2^b - 1 >= N-1 / Q-1 (masked rejection)
     int klarner_M;          // 0: exact Klarner (gcd(N,210)==1); else core edge M
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     int e = 0;
     {
         uint32_t* cnt = (uint32_t*)perm;
-        const int D = 2 * N - 1, n_lines = 3 * Q + 6 * N * D + 4 * D * D;
+        const int D = 2 * N - 1, NN = N * N, n_lines = 3 * NN + 6 * N * D + 4 * D * D;
         for (int w = lane; w < (n_lines + 3) / 4; w += 64) cnt[w] = 0;
         auto bump = [&](int line) { atomicAdd(&cnt[line >> 2], 1u << (8 * (line & 3))); };
         for (int c = lane; c < Q; c += 64) {
@@ -454,9 +455,9 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
             else i = st[3 * c], j = st[3 * c + 1], k = st[3 * c + 2];
             const int dij = i - j + N - 1, dik = i - k + N - 1, djk = j - k + N - 1, sij = i + j, sik = i + k, sjk = j + k;
             int base = 0;
-            bump(base + j * N + k), base += Q;
-            bump(base + i * N + k), base += Q;
-            bump(base + i * N + j), base += Q;
+            bump(base + j * N + k), base += NN;
+            bump(base + i * N + k), base += NN;
+            bump(base + i * N + j), base += NN;
             bump(base + k * D + dij), base += N * D;
             bump(base + k * D + sij), base += N * D;
             bump(base + j * D + dik), base += N * D;
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     const int lane = threadIdx.x;
     const int gl = lane & (G - 1), grp = lane / G;
     const long long chain = (long long)blockIdx.x * CPW + grp;
-    const int N = NC ? NC : a.N, Q = NC ? NC * NC : a.Q;
+    const int N = NC ? NC : a.N, NN = N * N, Q = NC ? NC * NC : a.Q;  // (the compile-time-N variants are dispatched for Q = N^2 only)
     const int full_pad = NC ? (NC + 3) & ~3 : a.full_pad;
     const int state_bytes = NC ? (MODE == MCQ_MODE_BOARD ? NC * NC : 3 * NC * NC) : a.state_bytes;
     bool active = chain < a.n_chains;
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
     constexpr bool NARROW = MODE == MCQ_MODE_FULL3D && NT > 0;  // N <= 16: 16-bit column words
     typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type colw_t;
     colw_t* colw = (colw_t*)(base + LDS_STATE) + full_pad;
-    uint16_t* qn = (uint16_t*)(colw + Q + full_pad);
+    uint16_t* qn = (uint16_t*)(colw + NN + full_pad);
 
     // ---- load the chain record ----
     uint32_t* rec = a.ws + crow * (long long)a.rec_words;
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
     } else {
         uint32_t* cw32 = base + LDS_STATE;  // the column table and its pads as 32-bit words
-        const int cwords = (int)((2 * full_pad + Q) * sizeof(colw_t) / 4);
+        const int cwords = (int)((2 * full_pad + NN) * sizeof(colw_t) / 4);
         for (int w = gl; w < cwords; w += G) cw32[w] = 0;
         for (int c = gl; c < Q; c += G) {
             const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
@@ -1899,6 +1900,16 @@ int validate(const mcq_params* p) {
             if (p->sets[t].init_plus1 < 0 || p->sets[t].init_plus1 > MCQ_INIT_KLARNER + 1) return fail(MCQ_EINVAL, "Unknown init_mode in sets");
         }
     }
+    if (p->n_queens < 0) return fail(MCQ_EINVAL, "negative n_queens");
+    if (p->n_queens > 0 && p->n_queens != p->N * p->N) {  // mcmc.py:6-18, 92-101: any Q <= N^3 with the random init; latin / klarner assume Q = N^2 (mcmc.py:21-25)
+        if (p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "n_queens applies to mcmc_type full_3d (a board has one queen per column)");
+        bool other_init = p->init != MCQ_INIT_RANDOM;
+        for (int64_t t = 0; t < p->n_sets && p->n_sets > 1; t++) other_init |= p->sets[t].init_plus1 != 0 && p->sets[t].init_plus1 != MCQ_INIT_RANDOM + 1;
+        if (other_init) return fail(MCQ_EINVAL, "latin / klarner initialization assumes Q = N^2");
+        if (p->n_queens < 2) return fail(MCQ_EINVAL, "n_queens must be at least 2 in this build");
+        if ((int64_t)p->n_queens >= (int64_t)p->N * p->N * p->N) return fail(MCQ_EINVAL, "n_queens must leave a free cell: Q < N^3 (the reference raises for Q > N^3 and never returns for Q = N^3)");
+        if (p->n_queens > 32767) return fail(MCQ_EINVAL, "n_queens above 32767 is not supported by this build");
+    }
     if (p->exchange_every < 0) return fail(MCQ_EINVAL, "negative exchange_every");
     if (p->exchange_every > 0) {
         const int R = p->exchange_replicas;
@@ -1912,11 +1923,15 @@ int validate(const mcq_params* p) {
     return MCQ_OK;
 }
 
+// queens of a full_3d chain: N * N unless the caller names a count (mcmc.py:6-18 State3DQueens(N, Q=...), random init only)
+int queens_of(const mcq_params* p) { return p->mode == MCQ_MODE_FULL3D && p->n_queens > 0 ? p->n_queens : p->N * p->N; }
+size_t state_bytes_of(const mcq_params* p) { return p->mode == MCQ_MODE_BOARD ? (size_t)p->N * p->N : (size_t)3 * queens_of(p); }
+
 // 64-byte multiple: the sweep reads and writes the MT words of a record in aligned 64-byte blocks
 #if defined(MCQ_EXP_LAST_TOUCH) || defined(MCQ_EXP_REC128)  // timing experiment: 128-byte records, so that a block's half of its line is known from its index
-int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 31) & ~31; }
+int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_of(p) + 3) / 4) + 31) & ~31; }
 #else
-int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((mcq_state_bytes(p->N, p->mode) + 3) / 4) + 15) & ~15; }
+int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_of(p) + 3) / 4) + 15) & ~15; }
 #endif
 
 size_t n_sets_of(const mcq_params* p) { return p->n_sets > 1 ? (size_t)p->n_sets : 1; }
@@ -1932,11 +1947,12 @@ constexpr size_t LADDER_BYTES = 16 * 8;       // replica exchange: the beta mult
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
 // side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
-int chain_lds_words_for(int N, int mode, bool narrow) {
-    const int Q = N * N, pad = (N + 3) & ~3;
+int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0) {
+    const int NN = N * N, pad = (N + 3) & ~3;
+    if (Q <= 0) Q = NN;  // full_3d: the queens (mcq_params.n_queens); N * N by default
     int w = LDS_STATE;
-    if (mode == MCQ_MODE_BOARD) w += (Q + 3) / 4 + (N + 2) / 4;
-    else w += (narrow ? (2 * pad + Q + 1) / 2 : 2 * pad + Q) + (Q + 1) / 2;
+    if (mode == MCQ_MODE_BOARD) w += (NN + 3) / 4 + (N + 2) / 4;
+    else w += (narrow ? (2 * pad + NN + 1) / 2 : 2 * pad + NN) + (Q + 1) / 2;
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
     // The chains of a wavefront make many accesses at the SAME offset of their slices (history staging, cold scalars, ring appends):
     // a stride of 4 mod 8 words puts the 8 chains of a 32-lane access group on 8 different banks; 0 mod 8 would serialise them
@@ -1951,7 +1967,7 @@ int chain_lds_words_for(int N, int mode, bool narrow) {
 
 int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* ws, KArgs* a) {
     memset(a, 0, sizeof *a);
-    a->N = p->N, a->Q = p->N * p->N, a->mode = p->mode, a->init = p->init, a->sched = p->sched, a->flags = p->flags, a->rng = p->rng;
+    a->N = p->N, a->Q = queens_of(p), a->NN = p->N * p->N, a->mode = p->mode, a->init = p->init, a->sched = p->sched, a->flags = p->flags, a->rng = p->rng;
     a->maskN = host_mask((unsigned)(p->N - 1)), a->maskQ = host_mask((unsigned)(a->Q - 1));
     a->klarner_M = 0;
     if (p->init == MCQ_INIT_KLARNER && gcd_int(p->N, 210) != 1) {
@@ -1962,12 +1978,12 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
             }
         if (a->klarner_M == 0) return fail(MCQ_EINVAL, "no Klarner core below N");
     }
-    a->state_bytes = (int)mcq_state_bytes(p->N, p->mode);
+    a->state_bytes = (int)state_bytes_of(p);
     a->rec_words = rec_words_for(p);
     // board: the diagonal probes read up to N-1 bytes before / after the heights; (N+2)/4 spare words on each
     // side keep those (discarded) reads inside the chain's own LDS slice.
     a->full_pad = (p->N + 3) & ~3;
-    a->chain_lds_words = chain_lds_words_for(p->N, p->mode, false);  // full_3d: the launcher picks the 16-bit layout where it applies
+    a->chain_lds_words = chain_lds_words_for(p->N, p->mode, false, a->Q);  // full_3d: the launcher picks the 16-bit layout where it applies
     a->beta_const = p->beta_const, a->beta_start = p->beta_start, a->beta_end = p->beta_end;
     a->n_steps = p->n_steps, a->n_chains = p->n_chains;
     a->patience = p->mode == MCQ_MODE_BOARD ? p->patience : -1;  // full_3d ignores early_stop_patience (experiments.py:199-279)
@@ -2046,8 +2062,8 @@ int launch_sweep_philox(const KArgs& a, hipStream_t s) {
         if constexpr (G == 8) {
             if (!a.red && (a.N + 3) / 4 == 3) {
                 KArgs b = a;
-                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
-                return a.N == 12 ? launch_sweep<MODE, G, false, 3, false, true, 12>(b, s) : launch_sweep<MODE, G, false, 3, false, true>(b, s);
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q);
+                return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 3, false, true, 12>(b, s) : launch_sweep<MODE, G, false, 3, false, true>(b, s);
             }
         }
         return a.red ? launch_sweep<MODE, G, false, 0, true, true>(a, s) : launch_sweep<MODE, G, false, 0, false, true>(a, s);
@@ -2071,9 +2087,9 @@ int launch_sweep_exchange(const KArgs& a, hipStream_t s) {
         if (a.N == 12) return launch_sweep<MODE, G, false, 3, false, false, 12, true>(a, s);
     }
     if constexpr (MODE == MCQ_MODE_FULL3D && G == 8) {
-        if (a.N == 12) {
+        if (a.N == 12 && a.Q == 144) {
             KArgs b = a;
-            b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+            b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q);
             return launch_sweep<MODE, G, false, 3, false, false, 12, true>(b, s);
         }
     }
@@ -2089,16 +2105,16 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             const int nt = (a.N + 3) / 4;
             if (a.red && nt == 3) {  // BASELINE config 3's shape with the reduced trace
                 KArgs b = a;
-                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
-                return a.N == 12 ? launch_sweep<MODE, G, false, 3, true, false, 12>(b, s) : launch_sweep<MODE, G, false, 3, true>(b, s);
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q);
+                return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 3, true, false, 12>(b, s) : launch_sweep<MODE, G, false, 3, true>(b, s);
             }
             if (!a.red && nt <= 4) {
                 KArgs b = a;
-                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q);
                 switch (nt) {
                 case 1: return launch_sweep<MODE, G, false, 1, false>(b, s);
                 case 2: return launch_sweep<MODE, G, false, 2, false>(b, s);
-                case 3: return a.N == 12 ? launch_sweep<MODE, G, false, 3, false, false, 12>(b, s) : launch_sweep<MODE, G, false, 3, false>(b, s);
+                case 3: return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 3, false, false, 12>(b, s) : launch_sweep<MODE, G, false, 3, false>(b, s);
                 default: return launch_sweep<MODE, G, false, 4, false>(b, s);
                 }
             }
@@ -2107,7 +2123,7 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         if constexpr (G == 4) {  // experiment: the 16-bit layout with two lanes around each of the two cells, six unrolled passes
             if (!a.red && (a.N + 1) / 2 == 6) {
                 KArgs b = a;
-                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true);
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q);
                 return launch_sweep<MODE, G, false, 6, false>(b, s);
             }
         }
@@ -2203,12 +2219,13 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         HIP_TRY(hipMemcpyAsync((void*)a.exch_ladder, p->exchange_ladder, (size_t)p->exchange_replicas * 8, hipMemcpyHostToDevice, s));
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     {  // behind the state: the permutation array of np.random.choice (full_3d random init), then the E0 line counters
-        const size_t D = 2 * (size_t)p->N - 1, lines = ((3 * (size_t)a.Q + 6 * p->N * D + 4 * D * D + 3) / 4) * 4;
+        const size_t D = 2 * (size_t)p->N - 1, lines = ((3 * (size_t)a.NN + 6 * p->N * D + 4 * D * D + 3) / 4) * 4;
         bool any_random = p->init == MCQ_INIT_RANDOM;
         for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) any_random |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
         const size_t perm = p->mode == MCQ_MODE_FULL3D && any_random ? (size_t)p->N * p->N * p->N * 2 : 0;
         init_lds += perm > lines ? perm : lines;
     }
+    if (init_lds > 160 * 1024) return fail(MCQ_EINVAL, "initial state does not fit in LDS (N^3 permutation array + 3 Q state bytes)");
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     if (p->n_steps > 0) {
@@ -2292,6 +2309,8 @@ size_t mcq_state_bytes(int32_t N, int32_t mode) {
     if (N < MCQ_MIN_N || N > MCQ_MAX_N) return 0;
     return mode == MCQ_MODE_BOARD ? (size_t)N * N : (size_t)3 * N * N;
 }
+
+size_t mcq_state_bytes_for(const mcq_params* p) { return validate(p) == MCQ_OK ? state_bytes_of(p) : 0; }
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
@@ -2434,7 +2453,7 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
     if (kernel_seconds) *kernel_seconds = 0.0;
     if (p->n_chains == 0) return MCQ_OK;
 
-    const size_t n = (size_t)p->n_chains, sb = mcq_state_bytes(p->N, p->mode);
+    const size_t n = (size_t)p->n_chains, sb = state_bytes_of(p);
     struct Buf {
         void** dev;
         void* host;

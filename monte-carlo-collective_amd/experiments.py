@@ -144,8 +144,8 @@ class QueensState:
     """Stand-in for State3DQueens: N, Q, queens[Q,3] and the occupied-cell set (mcmc.py:15-18, 101, 113-118)."""
 
     def __init__(self, N, queens, energy):
-        self.N, self.Q = N, N * N
         self.queens = np.asarray(queens, dtype=np.int64).reshape(-1, 3)
+        self.N, self.Q = N, len(self.queens)
         self.occ_set = {tuple(int(v) for v in q) for q in self.queens}
         self._energy = int(energy)
 
@@ -161,14 +161,14 @@ def _state(mode, N, row, energy):
 # the sweep
 # --------------------------------------------------------------------------------------------
 def run_chains(N, n_steps, init_mode, schedule_params, seeds, mcmc_type="full_3d", early_stop_patience=None,
-               trace=True, states=True, flags=0, lanes_per_chain=0):
+               trace=True, states=True, flags=0, lanes_per_chain=0, Q=None):
     """Lowest Python level: every chain of `seeds` in one GPU launch.
 
     Returns (result dict of NumPy arrays as described in include/mcq.h, kernel seconds)."""
     seeds = np.asarray(seeds)
     params = abi.make_params(N, n_steps, init_mode, schedule_params, len(seeds), mcmc_type=mcmc_type,
                              early_stop_patience=early_stop_patience, trace=trace, flags=flags,
-                             lanes_per_chain=lanes_per_chain)
+                             lanes_per_chain=lanes_per_chain, Q=Q)
     if seeds.size and (seeds.min() < 0 or seeds.max() > 2**32 - 1):
         raise ValueError("Seed must be between 0 and 2**32 - 1")
     return _lib.run_host(params, seeds.astype(np.uint32), trace=trace, states=states)
@@ -227,9 +227,7 @@ def metropolis_mcmc(N, n_steps, init_mode, beta_schedule, verbose=True, seed=Non
     """experiments.py:199-279 for one chain; early_stop_patience is accepted and ignored, as there."""
     if seed is None:
         raise ValueError("seed is required")
-    if Q is not None and Q != N * N:
-        raise ValueError(f"only Q = N^2 is supported, got Q={Q}, N^2={N * N}")
-    res, _ = run_chains(N, n_steps, init_mode, _params_of(beta_schedule, schedule_params), [seed], mcmc_type="full_3d")
+    res, _ = run_chains(N, n_steps, init_mode, _params_of(beta_schedule, schedule_params), [seed], mcmc_type="full_3d", Q=Q)
     d = _chain_dict(res, 0, abi.MODE_FULL3D, N)
     if verbose and n_steps > 0:
         print(d["final_energy"])

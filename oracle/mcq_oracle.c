@@ -414,8 +414,11 @@ static int full_attacks(cell_t a, cell_t b) {
     return same_ij | same_ik | same_jk | plane_k | plane_j | plane_i | space;
 }
 
-static int full_init(int N, int init, rng_t* rng, cell_t* q, uint8_t* occ) {
-    const int Q = N * N;
+/* queens of a full_3d chain: State3DQueens(N, Q=...) (mcmc.py:6-18); Q = N^2 unless the caller names a count */
+static int queens_of(const mcq_params* p) { return p->mode == MCQ_MODE_FULL3D && p->n_queens > 0 ? p->n_queens : p->N * p->N; }
+
+static int full_init(int N, int Q, int init, rng_t* rng, cell_t* q, uint8_t* occ) {
+    if (init != MCQ_INIT_RANDOM && Q != N * N) return -1; /* mcmc.py:21-25: latin / klarner assume Q = N^2 */
     memset(occ, 0, (size_t)N * N * N);
     if (init == MCQ_INIT_LATIN) { /* mcmc.py:28-34 */
         for (int i = 0; i < N; i++)
@@ -494,7 +497,7 @@ static int full_conflicts(int Q, const cell_t* q, int q_idx, cell_t at) {
 static int run_full_chain(const job_t* jb, int64_t r) {
     const mcq_params* p = jb->p;
     const mcq_outputs* o = jb->out;
-    const int N = p->N, Q = N * N;
+    const int N = p->N, Q = queens_of(p);
     cell_t* q = (cell_t*)malloc(sizeof(cell_t) * (size_t)Q * 2);
     uint8_t* occ = (uint8_t*)malloc((size_t)N * N * N);
     if (!q || !occ) {
@@ -506,7 +509,7 @@ static int run_full_chain(const job_t* jb, int64_t r) {
 
     rng_t rng;
     rng_seed(&rng, p->rng, jb->seeds[r]); /* experiments.py:200-201 */
-    if (full_init(N, p->init, &rng, q, occ) != 0) {
+    if (full_init(N, Q, p->init, &rng, q, occ) != 0) {
         free(q);
         free(occ);
         return MCQ_EINVAL;
@@ -728,7 +731,7 @@ static int run_board_chain_fast(const job_t* jb, int64_t r) {
 static int run_full_chain_fast(const job_t* jb, int64_t r) {
     const mcq_params* p = jb->p;
     const mcq_outputs* o = jb->out;
-    const int N = p->N, Q = N * N;
+    const int N = p->N, Q = queens_of(p);
     cell_t* q = (cell_t*)malloc(sizeof(cell_t) * (size_t)Q * 2);
     uint8_t* occ = (uint8_t*)malloc((size_t)N * N * N);
     uint8_t* cnt = (uint8_t*)malloc(lines_total(N));
@@ -739,7 +742,7 @@ static int run_full_chain_fast(const job_t* jb, int64_t r) {
     cell_t* best_q = q + Q;
     rng_t rng;
     rng_seed(&rng, p->rng, jb->seeds[r]);
-    if (full_init(N, p->init, &rng, q, occ) != 0) {
+    if (full_init(N, Q, p->init, &rng, q, occ) != 0) {
         free(q), free(occ), free(cnt);
         return MCQ_EINVAL;
     }
@@ -841,7 +844,7 @@ static void xchain_free(xchain_t* c) {
 
 static int xchain_init(xchain_t* c, const mcq_params* p, const mcq_outputs* o, const uint32_t* seeds, int64_t r, int fast, int rung) {
     memset(c, 0, sizeof *c);
-    c->p = p, c->o = o, c->r = r, c->fast = fast, c->N = p->N, c->Q = p->N * p->N, c->rung = rung;
+    c->p = p, c->o = o, c->r = r, c->fast = fast, c->N = p->N, c->Q = queens_of(p), c->rung = rung;
     const int N = c->N, Q = c->Q;
     rng_seed(&c->rng, p->rng, seeds[r]);
     if (fast) {
@@ -866,7 +869,7 @@ static int xchain_init(xchain_t* c, const mcq_params* p, const mcq_outputs* o, c
         c->occ = (uint8_t*)malloc((size_t)N * N * N);
         if (!c->q || !c->occ) return MCQ_ENOMEM;
         c->best_q = c->q + Q;
-        if (full_init(N, p->init, &c->rng, c->q, c->occ) != 0) return MCQ_EINVAL;
+        if (full_init(N, Q, p->init, &c->rng, c->q, c->occ) != 0) return MCQ_EINVAL;
         if (fast) {
             for (int t = 0; t < Q; t++) lines_add(&c->L, c->q[t].i, c->q[t].j, c->q[t].k, 1);
             c->E = lines_energy(&c->L);
@@ -1099,6 +1102,16 @@ static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq
     if (out->accept_bits && p->bits_stride < (p->n_steps + 63) / 64) return fail(MCQ_EINVAL, "bits_stride too small");
     if (p->trace == MCQ_TRACE_I32 && (!out->energy_hist || !out->accept_bits))
         return fail(MCQ_EINVAL, "trace requested without buffers");
+    if (p->n_queens < 0) return fail(MCQ_EINVAL, "negative n_queens");
+    if (p->n_queens > 0 && p->n_queens != p->N * p->N) {
+        if (p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "n_queens applies to mcmc_type full_3d (a board has one queen per column)");
+        int other_init = p->init != MCQ_INIT_RANDOM;
+        for (int64_t t = 0; t < p->n_sets && p->n_sets > 1; t++)
+            other_init |= p->sets[t].init_plus1 != 0 && p->sets[t].init_plus1 != MCQ_INIT_RANDOM + 1;
+        if (other_init) return fail(MCQ_EINVAL, "latin / klarner initialization assumes Q = N^2");
+        if (p->n_queens < 2) return fail(MCQ_EINVAL, "n_queens must be at least 2 in this build");
+        if ((int64_t)p->n_queens >= (int64_t)p->N * p->N * p->N) return fail(MCQ_EINVAL, "n_queens must leave a free cell: Q < N^3");
+    }
     if (p->exchange_every < 0) return fail(MCQ_EINVAL, "negative exchange_every");
     if (p->exchange_every > 0) {
         const int R = p->exchange_replicas;

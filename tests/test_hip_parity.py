@@ -35,6 +35,35 @@ def test_golden_chains(golden, lanes):
     assert n == len(golden.chains)
 
 
+@pytest.mark.parametrize("lanes", LANES)
+def test_golden_chains_with_other_queen_counts(golden, lanes):
+    """metropolis_mcmc(..., Q=...) (experiments.py:199-203): the reference's chains with Q != N^2 queens."""
+    for case in golden.chains_q:
+        p = util.params_for_case(case, lanes_per_chain=lanes)
+        res, _ = mcq_amd._lib.run_host(p, np.array([case["seed"]], dtype=np.uint32))
+        util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"hip G={lanes} vs reference {case}")
+
+
+def test_queen_counts_against_the_oracle():
+    """Q != N^2 at sizes the golden chains do not reach: many chains per launch, reduced trace, Philox, sets."""
+    sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}
+    for N, Q, n in ((12, 150, 70), (12, 1000, 24), (8, 3, 33), (16, 500, 17), (20, 40, 9), (32, 200, 5), (7, 342, 11)):
+        for rng in ("mt19937", "philox"):
+            p = abi.make_params(N, 1200, "random", sp, n, mcmc_type="full_3d", Q=Q, rng=rng)
+            seeds = abi.seeds_for(77 + Q, n)
+            want = oracle.run(p, seeds, fast=True, n_threads=8)
+            got, _ = mcq_amd._lib.run_host(p, seeds)
+            util.assert_results_equal(got, want, f"N={N} Q={Q} {rng}")
+            assert got["near_ties"].sum() == 0
+    p = abi.make_params(12, 800, "random", sp, 64, mcmc_type="full_3d", Q=100, trace="reduced")
+    seeds = abi.seeds_for(5, 64)
+    got, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced", states=False)
+    full = oracle.run(abi.make_params(12, 800, "random", sp, 64, mcmc_type="full_3d", Q=100), seeds, fast=True, n_threads=8)
+    st = mcq_amd.jobs.stats_from_trace(full, 800)
+    for k in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+        np.testing.assert_array_equal(got[k], st[k], err_msg=k)
+
+
 CASES = [
     # (N, mode, init, schedule, n_steps, n_chains, patience)
     (12, "board", "random", {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}, 3000, 150, None),

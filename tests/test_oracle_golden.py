@@ -22,6 +22,46 @@ def test_every_golden_chain(golden):
         util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle vs reference {case}")
 
 
+def test_golden_chains_with_other_queen_counts(golden):
+    """metropolis_mcmc(..., Q=...) / State3DQueens(N, Q=...) (experiments.py:199-203, mcmc.py:6-18, 92-101): 36 reference chains with
+    2 <= Q < N^3 queens, Q != N^2, random init; the naive scan and the line-counter variant."""
+    assert len(golden.chains_q) >= 36
+    for case in golden.chains_q:
+        p = util.params_for_case(case)
+        assert p.n_queens == case["Q"]
+        for fast in (False, True):
+            res = oracle.run(p, np.array([case["seed"]], dtype=np.uint32), fast=fast)
+            assert res["final_state"].shape == (1, 3 * case["Q"])
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
+
+
+def test_queen_count_errors():
+    """Where the reference raises (mcmc.py:21-25, 94-95) and where this build's limits are."""
+    sp = {"type": "constant", "beta_const": 1.0}
+    for init in ("latin", "klarner"):
+        with pytest.raises(ValueError, match=r"initialization assumes Q = N\^2"):
+            abi.make_params(6, 10, init, sp, 1, mcmc_type="full_3d", Q=20)
+    with pytest.raises(ValueError, match=r"cannot exceed N\^3"):
+        abi.make_params(3, 10, "random", sp, 1, mcmc_type="full_3d", Q=28)
+    for q in (1, 27):
+        with pytest.raises(ValueError, match="this build runs"):
+            abi.make_params(3, 10, "random", sp, 1, mcmc_type="full_3d", Q=q)
+    with pytest.raises(ValueError, match="full_3d"):
+        abi.make_params(6, 10, "random", sp, 1, mcmc_type="board", Q=20)
+    assert abi.make_params(6, 10, "latin", sp, 1, mcmc_type="full_3d", Q=36).n_queens == 0  # Q = N^2 is the default
+    import ctypes
+
+    import mcq_amd
+
+    L = mcq_amd._lib.lib()
+    p = abi.make_params(6, 10, "random", sp, 4, mcmc_type="full_3d", Q=20)
+    assert L.mcq_state_bytes_for(ctypes.byref(p)) == 60 and L.mcq_workspace_bytes(ctypes.byref(p)) > 0
+    p.init = abi.INIT["latin"]
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and b"assumes Q = N^2" in L.mcq_last_error()
+    with pytest.raises(ValueError, match=r"assumes Q = N\^2"):
+        oracle.run(p, np.arange(4, dtype=np.uint32))
+
+
 def test_early_stop_lengths(golden):
     """F4: board N=6 const beta=5 seed 7 patience 300 stops with 803 entries, best at 503."""
     case = next(c for c in golden.chains if c.get("patience") == 300)

@@ -27,15 +27,20 @@ class Golden:
     def chains(self):
         return self.manifest["chains"]
 
+    @property
+    def chains_q(self):
+        """full_3d chains with Q != N^2 queens (metropolis_mcmc(..., Q=...), experiments.py:199-203)"""
+        return self.manifest["chains_q"]
+
     def chain(self, case):
-        z = self.npz("chains")
+        z = self.npz("chains_q" if case["key"].startswith("q") else "chains")
         return {k: z[f"{case['key']}_{k}"] for k in
                 ("hist", "accept", "n_executed", "best_energy", "final_energy", "steps_to_best", "best_state", "final_state")}
 
 
 def params_for_case(case, n_chains=1, **kw):
     return abi.make_params(case["N"], case["n_steps"], case["init"], case["schedule"], n_chains,
-                           mcmc_type=case["mode"], early_stop_patience=case.get("patience"), **kw)
+                           mcmc_type=case["mode"], early_stop_patience=case.get("patience"), Q=case.get("Q"), **kw)
 
 
 def accept_bytes(bits_row, n_steps):

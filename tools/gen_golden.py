@@ -69,6 +69,7 @@ def run_chain(job):
             verbose=False,
             seed=case["seed"],
             early_stop_patience=case.get("patience"),
+            **({"Q": case["Q"]} if "Q" in case else {}),  # metropolis_mcmc(..., Q=...): experiments.py:199-203
         )
     hist = np.asarray(res["energy_history"], dtype=np.int32)
     acc = np.zeros(case["n_steps"], dtype=np.uint8)
@@ -182,6 +183,20 @@ def chain_cases():
     return cases
 
 
+def q_cases():
+    """full_3d chains with Q != N^2 queens (State3DQueens(N, Q=...), mcmc.py:6-18; random init only): a separate file
+    (chains_q.npz / manifest["chains_q"]) so that the other fixtures stay byte for byte what they were.
+    `python tools/gen_golden.py --only q` writes just these."""
+    cases = []
+    for N, Q, n_steps in ((3, 2, 400), (3, 20, 400), (4, 5, 600), (6, 20, 800), (6, 100, 800), (12, 60, 1000), (12, 300, 600), (17, 100, 500), (5, 124, 300)):
+        for seed in (42, 1042):
+            for sp in (SCHEDULES[1], SCHEDULES[0]):
+                cases.append({"mode": "full_3d", "init": "random", "schedule": sp, "N": N, "Q": Q, "seed": seed, "n_steps": n_steps})
+    for idx, c in enumerate(cases):
+        c["key"] = f"q{idx:03d}"
+    return cases
+
+
 def gen_beta(ref_path, out):
     """F5: float64 beta(step) tables of the five schedule closures."""
     ex = _ref(ref_path)
@@ -278,8 +293,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz), merged into the existing manifest")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if args.only == "q":
+        cases = q_cases()
+        with ProcessPoolExecutor(max_workers=args.workers) as pool:
+            results = list(pool.map(run_chain, [(args.reference, c) for c in cases], chunksize=2))
+        np.savez_compressed(os.path.join(OUT, "chains_q.npz"), **{f"{c['key']}_{k}": v for c, r in zip(cases, results) for k, v in r.items()})
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
+        manifest["chains_q"] = cases
+        with open(os.path.join(OUT, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print(f"wrote {len(cases)} Q != N^2 chains")
+        return
     manifest = {"generator": "tools/gen_golden.py", "reference": "galgantar/monte-carlo-collective @ 2026-01-09"}
 
     manifest["rng"] = gen_rng(OUT)
