@@ -120,3 +120,55 @@ def test_random_feature_combinations():
             for f in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
                 g = got[f][t] if len(k["sets"]) > 1 else got[f]
                 np.testing.assert_array_equal(g, st[f], err_msg=f"{what}: {f} of set {t}")
+
+
+def _round3_cases(n=int(os.environ.get("MCQ_FUZZ_R3_CASES", "140"))):
+    rng = np.random.default_rng(FUZZ_SEED + 3)
+    scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
+    out = []
+    for c in range(n):
+        mode = "board" if rng.random() < 0.5 else "full_3d"
+        N = int(rng.choice([2, 3, 3, 4, 4, 5, 5, 6, 9, 12, 17, 19, 24]))
+        if mode == "full_3d" and N > 17:
+            N = int(rng.integers(2, 18))
+        st = str(rng.choice(scheds))
+        sp = {"type": st, "beta_const": float(rng.choice([0.3, 1.0, 2.5]))} if st == "constant" else \
+            {"type": st, "beta_start": float(rng.choice([0.1, 0.5, 1.0])), "beta_end": float(rng.choice([2.0, 3.0, 6.0]))}
+        n_steps = int(rng.choice([1, 16, 33, 100, 300, 700])) if not FUZZ_LONG else int(rng.choice([300, 1500, 4000]))
+        Q = None
+        if mode == "full_3d" and N >= 2 and rng.random() < 0.5:
+            Q = int(rng.integers(2, min(N ** 3, 1500)))
+        init = "random" if Q is not None and Q != N * N else str(rng.choice(["random", "latin", "klarner"]))
+        exch = None
+        if rng.random() < 0.45:
+            R = int(rng.choice([2, 4, 8, 16]))
+            exch = (int(rng.choice([1, 2, 7, 50])), R, float(rng.choice([0.5, 0.8, 1.0])), float(rng.choice([1.0, 1.3, 2.0])))
+        lanes = int(rng.choice([0, 4, 8, 16]))
+        if exch and lanes and 64 // lanes < exch[1]:
+            lanes = 0
+        n_chains = (exch[1] if exch else 1) * int(rng.choice([1, 2, 5]))
+        out.append(dict(c=c, N=N, mode=mode, init=init, sp=sp, n_steps=n_steps, Q=Q, exch=exch, lanes=lanes, n_chains=n_chains,
+                        rng="philox" if rng.random() < 0.3 else "mt19937", trace=bool(rng.random() < 0.7), seed0=int(rng.integers(0, 2**31))))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_random_round3_feature_combinations():
+    """The round-3 features crossed at random: full_3d with Q != N^2 queens, replica exchange (ladders of 2..16, periods 1..50),
+    the small boards whose kernels look at five candidates, both streams, with and without a trace, every lane width."""
+    for k in _round3_cases():
+        what = str(k)
+        p = abi.make_params(k["N"], k["n_steps"], k["init"], k["sp"], k["n_chains"], mcmc_type=k["mode"], early_stop_patience=None,
+                            lanes_per_chain=k["lanes"], rng=k["rng"], Q=k["Q"], trace=k["trace"])
+        if k["exch"]:
+            every, R, lo, hi = k["exch"]
+            abi.set_exchange(p, every, lo * (hi / lo) ** (np.arange(R) / (R - 1)))
+        seeds = abi.seeds_for(k["seed0"], k["n_chains"])
+        want = oracle.run(p, seeds, trace=k["trace"], n_threads=8, fast=bool(k["c"] & 1))
+        got, _ = mcq_amd._lib.run_host(p, seeds, trace=k["trace"])
+        util.assert_results_equal(got, want, what, trace=k["trace"])
+        if k["exch"]:
+            for f in ("exchange_rung", "n_exchanges"):
+                np.testing.assert_array_equal(got[f], want[f], err_msg=f"{what}: {f}")
+        assert got["near_ties"].sum() == 0 and want["near_ties"].sum() == 0, what
