@@ -71,9 +71,12 @@ extern "C" {
 #define MCQ_FLAG_EXACT_EXP 1u        /* evaluate exp(-beta*dE) in float64 on every step (disable the float32 bracket) */
 #define MCQ_FLAG_SEQUENTIAL_DRAWS 2u /* HIP: draw every proposal word by word (disable the batched selection); for testing */
 
-/* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319). */
+/* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319; the reference itself is
+ * unbounded).  full_3d: column occupancy is one 32-bit word per column.  board: bit masks up to N = 32, a compare per probed
+ * height beyond (slower, any size whose N*N heights fit a wavefront's share of the LDS and whose accept flags fit a byte). */
 #define MCQ_MIN_N 2
-#define MCQ_MAX_N 32
+#define MCQ_MAX_N 32        /* mcmc_type full_3d */
+#define MCQ_MAX_N_BOARD 128 /* mcmc_type board */
 
 /* One set of a batched run: its beta schedule (run_beta_start_end_pairs loops over such pairs: experiments.py:741-846) and,
  * optionally, its own init mode. */

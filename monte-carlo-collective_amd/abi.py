@@ -28,7 +28,7 @@ TRACE_NONE, TRACE_I32, TRACE_REDUCED = 0, 1, 2
 FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
 
-MIN_N, MAX_N = 2, 32
+MIN_N, MAX_N, MAX_N_BOARD = 2, 32, 128  # include/mcq.h: full_3d up to 32, boards up to 128
 MAX_HIST_STRIDE = 1 << 24  # a full trace row (hist_stride entries) must stay below this: include/mcq.h
 
 
@@ -246,8 +246,9 @@ def make_params(N, n_steps, init_mode, schedule_params, n_chains, mcmc_type="ful
     if init_mode not in INIT:
         raise ValueError(f"Unknown init_mode: {init_mode}")
     N = int(N)
-    if not (MIN_N <= N <= MAX_N):
-        raise ValueError(f"N must be in [{MIN_N}, {MAX_N}], got {N}")
+    top = MAX_N_BOARD if mode_of(mcmc_type) == MODE_BOARD else MAX_N
+    if not (MIN_N <= N <= top):
+        raise ValueError(f"N must be in [{MIN_N}, {top}] for mcmc_type {mcmc_type}, got {N}")
     n_steps = int(n_steps)
     if n_steps < 0:
         raise ValueError("n_steps must be >= 0")

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     //   (2N - 1)^2 lines each: (i - j, i - k), (i - j, i + k), (i + j, i - k), (i + j, i + k)                space diagonals
     // The counters take the place of the permutation array (no longer needed).
     int e = 0;
-    {
+    if (N <= 32) {
         uint32_t* cnt = (uint32_t*)perm;
         const int D = 2 * N - 1, NN = N * N, n_lines = 3 * NN + 6 * N * D + 4 * D * D;
         for (int w = lane; w < (n_lines + 3) / 4; w += 64) cnt[w] = 0;
@@ -476,6 +476,46 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
                 const int c = (int)((x >> (8 * b)) & 0xffu);
                 e += c * (c - 1) / 2;
             }
+        }
+    } else {
+        // boards beyond N = 32 (MCQ_MAX_N_BOARD): all 13 families at once would not fit the LDS (30 N^2 bytes), so one family at a
+        // time in a (2N - 1)^2-byte array -- the same sum of c (c - 1) / 2 (the k-axis family holds one queen per line on a board)
+        uint32_t* cnt = (uint32_t*)perm;
+        const int D = 2 * N - 1, o = N - 1;
+        for (int f = 0; f < 13; f++) {
+            if (f == 2) continue;  // lines along k: the column (i, j) itself, one queen each
+            const int lines = f < 3 ? N * N : f < 9 ? N * D : D * D;
+            for (int w = lane; w < (lines + 3) / 4; w += 64) cnt[w] = 0;
+            __syncthreads();  // (a workgroup of one wavefront: orders the phases for the compiler as well)
+            for (int c = lane; c < Q; c += 64) {
+                const int i = c / N, j = c % N, k = st[c];
+                int line;
+                switch (f) {
+                case 0: line = j * N + k; break;
+                case 1: line = i * N + k; break;
+                case 3: line = k * D + (i - j + o); break;
+                case 4: line = k * D + (i + j); break;
+                case 5: line = j * D + (i - k + o); break;
+                case 6: line = j * D + (i + k); break;
+                case 7: line = i * D + (j - k + o); break;
+                case 8: line = i * D + (j + k); break;
+                case 9: line = (i - j + o) * D + (i - k + o); break;
+                case 10: line = (i - j + o) * D + (i + k); break;
+                case 11: line = (i + j) * D + (i - k + o); break;
+                default: line = (i + j) * D + (i + k); break;
+                }
+                atomicAdd(&cnt[line >> 2], 1u << (8 * (line & 3)));
+            }
+            __syncthreads();
+            for (int w = lane; w < (lines + 3) / 4; w += 64) {
+                const uint32_t x = cnt[w];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int c = (int)((x >> (8 * b)) & 0xffu);
+                    e += c * (c - 1) / 2;
+                }
+            }
+            __syncthreads();
         }
     }
     e = wave_sum(e);
@@ -1483,11 +1523,27 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                             const int m = gl + t * G, mN_ = __mul24(m, N);
                             probe(m, t + 1 < NT || m < N, hrow[m], hj[mN_], hd[mN_ + m], ha[mN_ - m]);
                         }
-                    } else {
+                    } else if (N <= 32) {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                         for (int m = gl; m < N; m += G) {
                             const int mN_ = __mul24(m, N);
                             probe(m, true, hrow[m], hj[mN_], hd[mN_ + m], ha[mN_ - m]);
+                        }
+                    } else {
+                        // boards beyond N = 32 (up to MCQ_MAX_N_BOARD): heights no longer index a 32-bit mask, so a probed height h at
+                        // in-plane distance d is compared: it attacks k iff |h - k| is 0 or d (mcmc_board.py:177-191).  Slower per probe;
+                        // these sizes are outside every BASELINE config.
+                        auto hits = [&](uint32_t h, uint32_t d) {
+                            const uint32_t xn = abs_diff((int)h, pc), xo = abs_diff((int)h, old_k);
+                            return (int)(xn == 0u || xn == d) - (int)(xo == 0u || xo == d);
+                        };
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                        for (int m = gl; m < N; m += G) {
+                            const int mN_ = __mul24(m, N);
+                            const uint32_t dr = abs_diff(m, j), dc = abs_diff(m, i);
+                            acc += hits(hrow[m], dr) + hits(hj[mN_], dc);
+                            acc += (unsigned)(m + dji) < (unsigned)N ? hits(hd[mN_ + m], dc) : 0;
+                            acc += (unsigned)(sij - m) < (unsigned)N ? hits(ha[mN_ - m], dc) : 0;
                         }
                     }
                     dE = group_sum<G>(acc) + 4;
@@ -1879,8 +1935,9 @@ unsigned host_mask(unsigned m) {
 int validate(const mcq_params* p) {
     if (!p) return fail(MCQ_EINVAL, "null params");
     if (p->abi_version != MCQ_ABI_VERSION) return fail(MCQ_EINVAL, "abi_version mismatch");
-    if (p->N < MCQ_MIN_N || p->N > MCQ_MAX_N) return fail(MCQ_EINVAL, "N out of range [2, 32]");
     if (p->mode != MCQ_MODE_BOARD && p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "unknown mcmc_type");
+    if (p->N < MCQ_MIN_N || p->N > (p->mode == MCQ_MODE_BOARD ? MCQ_MAX_N_BOARD : MCQ_MAX_N))
+        return fail(MCQ_EINVAL, "N out of range [2, 32] (full_3d) / [2, 128] (board)");
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL) return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
     if (p->rng != MCQ_RNG_MT19937_NUMPY && p->rng != MCQ_RNG_PHILOX4X32_10) return fail(MCQ_EINVAL, "unknown rng");
@@ -2134,6 +2191,8 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
             // (early stopping -- the reference's default early_stop_patience = 100000 -- has its own unrolled variants for the
             // sizes that default to 4 lanes)
+            if (pat && !a.red && a.N <= 5)  // (five candidates for new_k, like the plain variants below)
+                return a.N <= 4 ? launch_sweep<MODE, G, true, 1, false, false, 0, false, true>(a, s) : launch_sweep<MODE, G, true, 2, false, false, 0, false, true>(a, s);
             if (pat && !a.red) switch ((a.N + G - 1) / G) {
                 case 1: return launch_sweep<MODE, G, true, 1, false>(a, s);
                 case 2: return launch_sweep<MODE, G, true, 2, false>(a, s);
@@ -2160,10 +2219,10 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             if (!pat && a.red && a.N == 24) return launch_sweep<MODE, G, false, 3, true, false, 24>(a, s);  // BASELINE config 5: the beta-pair driver's shape (N = 24, reduced trace)
             if (!pat && a.red && a.N > 16 && a.N <= 24) return launch_sweep<MODE, G, false, 3, true>(a, s);
             if (!pat && a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, false, 2, true>(a, s);
-            if (!pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
-            if (!pat && !a.red && a.N > 8) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
-            if (pat && !a.red && a.N > 16) return a.N <= 24 ? launch_sweep<MODE, G, true, 3, false>(a, s) : launch_sweep<MODE, G, true, 4, false>(a, s);
-            if (pat && !a.red && a.N > 8) return launch_sweep<MODE, G, true, 2, false>(a, s);
+            if (!pat && !a.red && a.N > 16 && a.N <= 32) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
+            if (!pat && !a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
+            if (pat && !a.red && a.N > 16 && a.N <= 32) return a.N <= 24 ? launch_sweep<MODE, G, true, 3, false>(a, s) : launch_sweep<MODE, G, true, 4, false>(a, s);
+            if (pat && !a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, true, 2, false>(a, s);
         }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
@@ -2219,7 +2278,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         HIP_TRY(hipMemcpyAsync((void*)a.exch_ladder, p->exchange_ladder, (size_t)p->exchange_replicas * 8, hipMemcpyHostToDevice, s));
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     {  // behind the state: the permutation array of np.random.choice (full_3d random init), then the E0 line counters
-        const size_t D = 2 * (size_t)p->N - 1, lines = ((3 * (size_t)a.NN + 6 * p->N * D + 4 * D * D + 3) / 4) * 4;
+        const size_t D = 2 * (size_t)p->N - 1, lines = p->N <= 32 ? ((3 * (size_t)a.NN + 6 * p->N * D + 4 * D * D + 3) / 4) * 4 : ((D * D + 3) / 4) * 4;  // N > 32: one family of lines at a time
         bool any_random = p->init == MCQ_INIT_RANDOM;
         for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) any_random |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
         const size_t perm = p->mode == MCQ_MODE_FULL3D && any_random ? (size_t)p->N * p->N * p->N * 2 : 0;
@@ -2306,7 +2365,7 @@ int32_t mcq_effective_lanes(const mcq_params* p) { return validate(p) == MCQ_OK 
 int32_t mcq_device_simds(void) { return device_simds(); }
 
 size_t mcq_state_bytes(int32_t N, int32_t mode) {
-    if (N < MCQ_MIN_N || N > MCQ_MAX_N) return 0;
+    if (N < MCQ_MIN_N || N > (mode == MCQ_MODE_BOARD ? MCQ_MAX_N_BOARD : MCQ_MAX_N)) return 0;
     return mode == MCQ_MODE_BOARD ? (size_t)N * N : (size_t)3 * N * N;
 }
 

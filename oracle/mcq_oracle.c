@@ -1084,7 +1084,7 @@ int mcq_oracle_run_fast(const mcq_params* p, const uint32_t* seeds, const mcq_ou
 static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, int n_threads, int fast) {
     if (!p || !seeds || !out) return fail(MCQ_EINVAL, "null argument");
     if (p->abi_version != MCQ_ABI_VERSION) return fail(MCQ_EINVAL, "abi_version mismatch");
-    if (p->N < MCQ_MIN_N || p->N > MCQ_MAX_N) return fail(MCQ_EINVAL, "N out of range");
+    if (p->N < MCQ_MIN_N || p->N > (p->mode == MCQ_MODE_BOARD ? MCQ_MAX_N_BOARD : MCQ_MAX_N)) return fail(MCQ_EINVAL, "N out of range");
     if (p->mode != MCQ_MODE_BOARD && p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "unknown mcmc_type");
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL)

@@ -58,7 +58,7 @@ def test_pure_helpers_without_gpu():
     p = mcq_amd.abi.make_params(12, 1000, "random", {"type": "constant", "beta_const": 1.0}, 10, mcmc_type="board")
     # beta table + c32 table + pacing table (2048 SIMD rows of 16 words) + exchange ladder (16 doubles) + chain records (628 + 36 words, rounded up to 64 bytes)
     assert L.mcq_workspace_bytes(ctypes.byref(p)) == 8192 + 4096 + 2048 * 16 * 4 + 128 + 10 * 672 * 4
-    p.N = 99
+    p.N = 200
     assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0
     assert b"N out of range" in L.mcq_last_error()
 

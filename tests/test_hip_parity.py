@@ -44,6 +44,26 @@ def test_golden_chains_with_other_queen_counts(golden, lanes):
         util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"hip G={lanes} vs reference {case}")
 
 
+def test_golden_boards_beyond_32(golden):
+    """Boards up to N = 128 (compare-based probes, E0 family by family): the reference's chains at N = 33..100, every lane width that
+    fits the LDS, and N = 101..128 against the oracle."""
+    for case in golden.chains_big:
+        for lanes in (0, 8, 16) + ((4,) if case["N"] <= 40 else ()):
+            p = util.params_for_case(case, lanes_per_chain=lanes)
+            res, _ = mcq_amd._lib.run_host(p, np.array([case["seed"]], dtype=np.uint32))
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"hip G={lanes} vs reference {case}")
+    sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}
+    for N, init, n, rng, patience in ((128, "random", 9, "mt19937", None), (126, "klarner", 5, "mt19937", 40), (101, "latin", 6, "philox", None), (65, "random", 20, "mt19937", None)):
+        p = abi.make_params(N, 600, init, sp, n, mcmc_type="board", rng=rng, early_stop_patience=patience)
+        seeds = abi.seeds_for(400 + N, n)
+        want = oracle.run(p, seeds, fast=True, n_threads=8)
+        got, _ = mcq_amd._lib.run_host(p, seeds)
+        util.assert_results_equal(got, want, f"N={N} {init} {rng}")
+        assert got["near_ties"].sum() == 0
+    with pytest.raises(ValueError, match="does not fit in LDS"):
+        mcq_amd._lib.run_host(abi.make_params(128, 10, "random", sp, 4, mcmc_type="board", lanes_per_chain=4), abi.seeds_for(1, 4))
+
+
 def test_queen_counts_against_the_oracle():
     """Q != N^2 at sizes the golden chains do not reach: many chains per launch, reduced trace, Philox, sets."""
     sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}

@@ -35,6 +35,22 @@ def test_golden_chains_with_other_queen_counts(golden):
             util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
 
 
+def test_golden_boards_beyond_32(golden):
+    """State3DQueensBoard is unbounded (mcmc_board.py:12); this build runs boards up to N = 128: 13 reference chains at N = 33..100
+    (random, latin, klarner with its fallback core, an early stop), the naive scan and the line-counter variant."""
+    assert len(golden.chains_big) >= 13
+    for case in golden.chains_big:
+        p = util.params_for_case(case)
+        for fast in (False, True):
+            res = oracle.run(p, np.array([case["seed"]], dtype=np.uint32), fast=fast)
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
+    sp = {"type": "constant", "beta_const": 1.0}
+    abi.make_params(128, 10, "random", sp, 1, mcmc_type="board")
+    for N, mode in ((129, "board"), (33, "full_3d")):
+        with pytest.raises(ValueError, match="N must be in"):
+            abi.make_params(N, 10, "random", sp, 1, mcmc_type=mode)
+
+
 def test_queen_count_errors():
     """Where the reference raises (mcmc.py:21-25, 94-95) and where this build's limits are."""
     sp = {"type": "constant", "beta_const": 1.0}

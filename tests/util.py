@@ -32,8 +32,13 @@ class Golden:
         """full_3d chains with Q != N^2 queens (metropolis_mcmc(..., Q=...), experiments.py:199-203)"""
         return self.manifest["chains_q"]
 
+    @property
+    def chains_big(self):
+        """board chains beyond N = 32 (the reference is unbounded, mcmc_board.py:12)"""
+        return self.manifest["chains_big"]
+
     def chain(self, case):
-        z = self.npz("chains_q" if case["key"].startswith("q") else "chains")
+        z = self.npz("chains_q" if case["key"].startswith("q") else "chains_big" if case["key"].startswith("big") else "chains")
         return {k: z[f"{case['key']}_{k}"] for k in
                 ("hist", "accept", "n_executed", "best_energy", "final_energy", "steps_to_best", "best_state", "final_state")}
 

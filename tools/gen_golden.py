@@ -197,6 +197,19 @@ def q_cases():
     return cases
 
 
+def big_cases():
+    """board chains beyond N = 32 (State3DQueensBoard is unbounded, mcmc_board.py:12; this build runs boards up to N = 128):
+    chains_big.npz / manifest["chains_big"], `python tools/gen_golden.py --only big`."""
+    cases = []
+    for N, init, n_steps in ((33, "random", 300), (33, "klarner", 200), (40, "latin", 200), (47, "klarner", 150), (64, "random", 150), (100, "random", 60)):
+        for seed in (42, 1042):
+            cases.append({"mode": "board", "init": init, "schedule": SCHEDULES[1], "N": N, "seed": seed, "n_steps": n_steps})
+    cases.append({"mode": "board", "init": "random", "schedule": SCHEDULES[0], "N": 36, "seed": 7, "n_steps": 400, "patience": 60})
+    for idx, c in enumerate(cases):
+        c["key"] = f"big{idx:03d}"
+    return cases
+
+
 def gen_beta(ref_path, out):
     """F5: float64 beta(step) tables of the five schedule closures."""
     ex = _ref(ref_path)
@@ -293,20 +306,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--workers", type=int, default=8)
-    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz), merged into the existing manifest")
+    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz); 'big': only the boards beyond N = 32 (chains_big.npz); merged into the existing manifest")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    if args.only == "q":
-        cases = q_cases()
+    if args.only in ("q", "big"):
+        name = "chains_" + args.only
+        cases = q_cases() if args.only == "q" else big_cases()
         with ProcessPoolExecutor(max_workers=args.workers) as pool:
             results = list(pool.map(run_chain, [(args.reference, c) for c in cases], chunksize=2))
-        np.savez_compressed(os.path.join(OUT, "chains_q.npz"), **{f"{c['key']}_{k}": v for c, r in zip(cases, results) for k, v in r.items()})
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **{f"{c['key']}_{k}": v for c, r in zip(cases, results) for k, v in r.items()})
         with open(os.path.join(OUT, "manifest.json")) as f:
             manifest = json.load(f)
-        manifest["chains_q"] = cases
+        manifest[name] = cases
         with open(os.path.join(OUT, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
-        print(f"wrote {len(cases)} Q != N^2 chains")
+        print(f"wrote {len(cases)} chains to {name}.npz")
         return
     manifest = {"generator": "tools/gen_golden.py", "reference": "galgantar/monte-carlo-collective @ 2026-01-09"}
 
