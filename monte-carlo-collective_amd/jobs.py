@@ -57,6 +57,16 @@ def lone_ms(N, lanes):
     return t[{4: 0, 8: 1, 16: 2}[int(lanes)]] * (max(int(N), 24) / 24.0)
 
 
+def _lds_bytes_per_wave(N, lanes):
+    """LDS of one board wavefront (csrc: chain_lds_words_for): staging 16 + scalars 4 + ring 96 words, the heights, a pad; a slice is a
+    multiple of 4 words and never 0 mod 8."""
+    w = 116 + (N * N + 3) // 4 + (N + 2) // 4
+    w = (w + 3) & ~3
+    if w % 8 == 0:
+        w += 4
+    return (64 // lanes) * w * 4
+
+
 def plan_lanes(shapes, simds, default_lanes):
     """Lanes per chain for launches that run side by side on one device.  `shapes`: one (N, n_chains, mode) per launch;
     `default_lanes(mode, N)`: the library's choice for a device full of that launch.  The library picks lanes for a launch on
@@ -74,6 +84,16 @@ def plan_lanes(shapes, simds, default_lanes):
     total = lambda pl: sum(waves(n, g) for (_, n, _), g in zip(shapes, pl))
     board = [m == abi.MODE_BOARD for _, _, m in shapes]
     plan = [int(default_lanes(m, N)) for N, _, m in shapes]
+    # Boards of N = 13..20 default to 8 lanes because at 4 their LDS slices (12-14 KB per wavefront) leave a CU 11-13 wavefronts
+    # when such a launch has the device to itself.  In a MIX with smaller boards the light wavefronts fill what the heavy ones
+    # leave, and 4 lanes -- 16 chains per wavefront, two thirds of the instructions per move -- win: measure_min_energy_vs_N at
+    # 8 192 chains per cell 1 156 -> 1 097 ms (profiles/r03_lane_plan.txt).  The test is the average LDS per wavefront of the list.
+    if sum(board) >= 2:
+        four = [4 if b and N <= 20 else g for (N, _, _), b, g in zip(shapes, board, plan)]
+        w4 = [waves(n, g) for (_, n, _), g in zip(shapes, four)]
+        lds = sum(w * _lds_bytes_per_wave(N, g) for (N, _, _), g, w, b in zip(shapes, four, w4, board) if b)
+        if lds <= 10.6 * 1024 * sum(w for w, b in zip(w4, board) if b):
+            plan = four
     if total(plan) > cap:
         four = [4 if b else g for b, g in zip(board, plan)]
         if total(four) <= cap:

@@ -26,9 +26,14 @@ def test_lane_plan_of_side_by_side_launches():
     assert _waves(c4, [_default(m, N) for N, _, m in c4]) > cap
     plan = jobs.plan_lanes(c4, simds, _default)
     assert plan == [4] * 18 and _waves(c4, plan) <= cap
-    # the same cells with 8 192 chains each never fit: the library defaults stand
+    # the same cells with 8 192 chains each: several rounds whatever the lanes, but in this mix of light and heavy wavefronts 4 lanes
+    # (16 chains per wavefront) beat the 8 that N = 13..20 would take on their own ...
     big = [(N, 24576, abi.MODE_BOARD) for N in range(3, 21)]
-    assert jobs.plan_lanes(big, simds, _default) == [_default(m, N) for N, _, m in big]
+    assert jobs.plan_lanes(big, simds, _default) == [4] * 18
+    # ... which a list of heavy launches alone does not get (their LDS slices would leave the CUs 11 wavefronts), nor N > 20
+    heavy = [(N, 24576, abi.MODE_BOARD) for N in range(17, 21)]
+    assert jobs.plan_lanes(heavy, simds, _default) == [8] * 4
+    assert jobs.plan_lanes([(24, 16384, abi.MODE_BOARD), (12, 16384, abi.MODE_BOARD), (6, 16384, abi.MODE_BOARD)], simds, _default) == [8, 4, 4]
     # a lone small launch: more lanes while the device stays under half full, and only where the table says the step gets shorter
     assert jobs.plan_lanes([(17, 512, abi.MODE_BOARD)], simds, _default) == [16]
     assert jobs.plan_lanes([(24, 16384, abi.MODE_BOARD)], simds, _default) == [8]
