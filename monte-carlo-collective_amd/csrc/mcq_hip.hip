@@ -1234,6 +1234,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             // stream upkeep runs for every chain of the wavefront together (cadence: see LOW_WATER above)
             auto upkeep = [&]() {
                 STAMP(0);
+                STAMP_COUNT(11);  // (diagnostic build: upkeep events of the wavefront)
                 if constexpr (PHILOX) {
                     if (rng.gen - rng.pos <= room_limit) rng.generate();
                 } else {
@@ -2409,8 +2410,8 @@ int mcq_run_device_timed(const mcq_params* p, const uint32_t* seeds, const mcq_o
         HIP_TRY(hipMemcpy(h, g_dbg, 96, hipMemcpyDeviceToHost));
         const char* names[8] = {"loop", "stream_upkeep", "draws", "dE", "accept", "apply+history", "-", "-"};
         fprintf(stderr, "STAMP word-by-word draws: %llu of %llu wavefront-steps (%.3f %%)\n", h[6], h[7], 100.0 * h[6] / (h[7] ? h[7] : 1));
-        fprintf(stderr, "STAMP float64 accept path %.3f %%, improvement path %.3f %%, second triple (full_3d) %.3f %% of the wavefront-steps\n",
-                100.0 * h[8] / (h[7] ? h[7] : 1), 100.0 * h[9] / (h[7] ? h[7] : 1), 100.0 * h[10] / (h[7] ? h[7] : 1));
+        fprintf(stderr, "STAMP float64 accept path %.3f %%, improvement path %.3f %%, second triple (full_3d) %.3f %%, stream upkeep %.1f %% of the wavefront-steps\n",
+                100.0 * h[8] / (h[7] ? h[7] : 1), 100.0 * h[9] / (h[7] ? h[7] : 1), 100.0 * h[10] / (h[7] ? h[7] : 1), 100.0 * h[11] / (h[7] ? h[7] : 1));
         unsigned long long tot = 0;
         for (int k = 0; k < 6; k++) tot += h[k];
         for (int k = 0; k < 6; k++) fprintf(stderr, "STAMP %-14s %14llu  %5.1f %%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
