@@ -46,6 +46,12 @@
 //   * the step is bound by instruction issue (four wavefronts per SIMD): the hot
 //     loop is written for few instructions per step, and the sizes of BASELINE's configs (N = 12,
 //     N = 24) have instantiations with N as a compile-time constant.
+//   * one chain that leaves the batched draw stalls the 15 (7) that share its wavefront, so the rare paths are kept
+//     short: the word-by-word draw goes on from what the batched attempt established (i, j and old_k; q and the
+//     examined triples) instead of starting over, and boards up to N = 5 look at five candidates for new_k.
+//   * beyond the reference's drivers: full_3d with Q != N^2 queens (mcq_params.n_queens), boards up to N = 128
+//     (compare-based probes beyond 32), and -- not modes of the reference, never defaults -- the Philox stream and
+//     replica exchange between the chains of a wavefront (mcq_params.exchange_every).
 //
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include <hip/hip_runtime.h>
