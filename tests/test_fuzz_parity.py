@@ -128,7 +128,7 @@ def _round3_cases(n=int(os.environ.get("MCQ_FUZZ_R3_CASES", "140"))):
     out = []
     for c in range(n):
         mode = "board" if rng.random() < 0.5 else "full_3d"
-        N = int(rng.choice([2, 3, 3, 4, 4, 5, 5, 6, 9, 12, 17, 19, 24]))
+        N = int(rng.choice([2, 3, 3, 4, 4, 5, 5, 6, 9, 12, 17, 19, 24, 33, 40, 57, 64, 100]))  # boards beyond 32: compare-based probes
         if mode == "full_3d" and N > 17:
             N = int(rng.integers(2, 18))
         st = str(rng.choice(scheds))
@@ -146,6 +146,10 @@ def _round3_cases(n=int(os.environ.get("MCQ_FUZZ_R3_CASES", "140"))):
         lanes = int(rng.choice([0, 4, 8, 16]))
         if exch and lanes and 64 // lanes < exch[1]:
             lanes = 0
+        if N > 32:  # the heights of 64 / lanes chains must fit the LDS
+            lanes = 0 if (exch and exch[1] > 4) or N <= 64 else 16
+            if exch and exch[1] > 8 and N > 64:
+                exch = None
         n_chains = (exch[1] if exch else 1) * int(rng.choice([1, 2, 5]))
         out.append(dict(c=c, N=N, mode=mode, init=init, sp=sp, n_steps=n_steps, Q=Q, exch=exch, lanes=lanes, n_chains=n_chains,
                         rng="philox" if rng.random() < 0.3 else "mt19937", trace=bool(rng.random() < 0.7), seed0=int(rng.integers(0, 2**31))))
