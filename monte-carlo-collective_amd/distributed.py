@@ -121,15 +121,17 @@ def summary_from_counters(counters, mins):
 
 
 def unpack_job(host, lay):
-    """Reduced fields of one job from the packed tensor copied to the host (NumPy int64)."""
+    """Reduced fields of one job from the packed tensor copied to the host (NumPy int64).  The arrays are VIEWS of `host` (66 MB
+    for BASELINE configs[4]: copying them out again cost 9 ms of a 25 ms reduce, profiles/r03_reduce_path.txt); the caller hands
+    over a host array of its own per reduce, which the views keep alive."""
     out = {"summary": summary_from_counters(host[lay.counters:lay.counters + N_COUNTERS], host[lay.mins:lay.mins + lay.world])}
     if lay.per_chain:
-        out["best_energy"] = host[lay.best:lay.best + lay.n_runs].copy()
-        out["steps_to_best"] = host[lay.stb:lay.stb + lay.n_runs].copy()
+        out["best_energy"] = host[lay.best:lay.best + lay.n_runs]
+        out["steps_to_best"] = host[lay.stb:lay.stb + lay.n_runs]
     if lay.stats:
         L = lay.n_steps + 1
         for k, name in enumerate(STAT_FIELDS):
-            out[name] = host[lay.stat0 + k * L:lay.stat0 + (k + 1) * L].copy()
+            out[name] = host[lay.stat0 + k * L:lay.stat0 + (k + 1) * L]
     return out
 
 

@@ -35,8 +35,13 @@ def make_job(N, n_steps, init_mode, schedule_params, n_runs, base_seed, mcmc_typ
 
 def _stopped_hist(hist_len, n_steps, xp, **kw):
     """step_stopped[e] = chains that stopped early with e as the entry they did not append (hist_len == e <= n_steps)."""
-    hl = hist_len[hist_len <= n_steps]
-    return xp.bincount(hl, minlength=n_steps + 1, **kw)[: n_steps + 1]
+    if xp is np:
+        hl = hist_len[hist_len <= n_steps]
+        return xp.bincount(hl, minlength=n_steps + 1, **kw)[: n_steps + 1]
+    # torch, on the device: a scatter-add with the full-length chains parked in a spare slot -- no boolean indexing and no bincount,
+    # each of which waits for the device to learn a size
+    idx = hist_len.to(xp.int64).clamp(max=n_steps + 1)
+    return xp.zeros(n_steps + 2, dtype=xp.int64, device=hist_len.device).scatter_add_(0, idx, xp.ones_like(idx))[: n_steps + 1]
 
 
 # Step time of ONE board wavefront with the SIMD to itself, ms per 20 000 steps, by N and lanes per chain (4, 8, 16): the measure a
@@ -116,6 +121,7 @@ class _Launch:
     def __init__(self, job_ids, run, n_local, cps):
         self.job_ids, self.run, self.n_local, self.cps = job_ids, run, n_local, cps
         self.stream = None
+        self.no_stops = None  # a zero step_stopped array, shared by the launch's jobs when none of its chains can stop early
 
 
 class JobSet:
@@ -136,6 +142,7 @@ class JobSet:
                                                        per_chain=True, stats=want == "stats")
         self.trace = {"summary": False, "stats": "reduced", "histories": True}[want]
         self.launches, self.local = [], [None] * len(self.jobs)
+        self._host, self._flip = [None, None], 0
         self.launch_seconds = 0.0
         if runner is None:
             self._allocate(lanes_per_chain, rng)
@@ -187,6 +194,8 @@ class JobSet:
 
         self.launches.sort(key=lambda la: -est(la))
         self.buf = torch.zeros(self.total_words, dtype=torch.int64, device=self.device)
+        # page-locked host copies of the packed tensor, used in turn by reduce(); allocated here, outside anybody's timed region
+        self._host = [torch.empty(self.total_words, dtype=torch.int64, pin_memory=True) for _ in range(2)]
 
     def launch(self):
         """Enqueue every launch on its stream; returns immediately (GPU path) or after the injected runner has run."""
@@ -218,7 +227,12 @@ class JobSet:
                 if self.want == "stats":
                     for k in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
                         r[k] = t[k][s] if len(la.job_ids) > 1 else t[k]
-                    r["step_stopped"] = _stopped_hist(r["hist_len"], n_steps, torch)
+                    if int(la.run.p.patience) < 0 or int(la.run.p.patience) > n_steps:  # no chain of this launch can stop early
+                        if la.no_stops is None:
+                            la.no_stops = torch.zeros(n_steps + 1, dtype=torch.int64, device=self.device)
+                        r["step_stopped"] = la.no_stops
+                    else:
+                        r["step_stopped"] = _stopped_hist(r["hist_len"], n_steps, torch)
                 out[i] = r
         return out
 
@@ -277,10 +291,26 @@ class JobSet:
             else:
                 r = {k: v.to(buf.device) for k, v in r.items()}
             dm.pack_job(buf, lay, self.rank, self.shards[i][1], r, torch)
-        if buf.device.type == "cuda" and self.world > 1 and self.dist.get_backend() != "nccl":
-            buf = buf.cpu()  # a host-side process group (gloo: tests with several ranks on one GPU) reduces host tensors
-        dm.all_reduce_packed(buf, self.dist)
-        host = buf.cpu().numpy()
+        if buf.device.type == "cuda":
+            # The results come back through one of two page-locked host buffers of the JobSet, used in turn (so the arrays of a
+            # reduce stay intact through the next one and are overwritten by the one after: copy what must live longer).  A fresh
+            # pageable array per reduce -- 66 MB for BASELINE configs[4] -- cost 10-20 ms of page faults and a slower copy on top of
+            # the 88 ms sweep of that config's per-GPU shape (profiles/r03_reduce_path.txt).
+            self._flip ^= 1
+            if self._host[self._flip] is None:
+                self._host[self._flip] = torch.empty(self.total_words, dtype=torch.int64, pin_memory=True)
+            h = self._host[self._flip]
+            if self.world > 1 and self.dist.get_backend() != "nccl":
+                h.copy_(buf)  # a host-side process group (gloo: tests with several ranks on one GPU) reduces host tensors
+                dm.all_reduce_packed(h, self.dist)
+            else:
+                dm.all_reduce_packed(buf, self.dist)
+                h.copy_(buf, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            host = h.numpy()
+        else:
+            dm.all_reduce_packed(buf, self.dist)
+            host = buf.numpy()
         out = [dm.unpack_job(host, lay) for lay in self.layouts]
         if self.want == "histories":
             self._attach_histories(out)
