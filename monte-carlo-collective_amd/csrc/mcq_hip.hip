@@ -150,6 +150,7 @@ struct KArgs {
     long long exch_every;     // replica exchange: period in steps (0: off)
     int exch_R;               // rungs of a ladder
     int low_water;            // stream upkeep runs when some chain of the wavefront holds fewer ready words than this
+    int init_words;           // init kernel: LDS words per chain
     const double* exch_ladder;  // [exch_R] beta multipliers per rung (workspace)
 };
 
@@ -195,24 +196,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
-// Stream used by the init kernel: one wavefront per chain, the current 64-word block kept in a
+// Stream used by the init kernel: L lanes per chain (64 / L chains per wavefront), the current L-word block kept in a
 // register per lane, one ds_bpermute per draw.
 struct InitRng {
     uint32_t* mt;
     uint32_t win;
-    int pos, gen_end, lane;
+    int pos, gen_end, sub, gbase, L;  // sub: lane inside the chain's group; gbase: first lane of the group
     bool philox;
     uint32_t key;
 
     __device__ __forceinline__ void fill(int base) {
-        if (philox) {  // word base + lane of the chain's Philox stream (an init draws far fewer than 2^32 words)
+        if (philox) {  // word base + sub of the chain's Philox stream (an init draws far fewer than 2^32 words)
             uint32_t o[4];
-            const uint32_t w = (uint32_t)(base + lane);
+            const uint32_t w = (uint32_t)(base + sub);
             philox4x32_10(w >> 2, 0u, key, o);
             win = (w & 2u) ? ((w & 1u) ? o[3] : o[2]) : ((w & 1u) ? o[1] : o[0]);
             return;
         }
-        const int i = base + lane;
+        const int i = base + sub;
         if (i < MT_N) {
             uint32_t v;
             if (base < gen_end) {
@@ -223,12 +224,12 @@ struct InitRng {
             }
             win = mt_temper(v);
         }
-        if (base >= gen_end) gen_end = base + 64 > MT_N ? MT_N : base + 64;
+        if (base >= gen_end) gen_end = base + L > MT_N ? MT_N : base + L;
     }
     __device__ __forceinline__ uint32_t next() {
-        const int off = pos & 63;
+        const int off = pos & (L - 1);
         if (off == 0) fill(pos);
-        const uint32_t w = (uint32_t)__shfl((int)win, off, 64);
+        const uint32_t w = (uint32_t)__shfl((int)win, gbase + off, 64);
         pos++;
         if (!philox && pos == MT_N) pos = 0, gen_end = 0;
         return w;
@@ -349,29 +350,44 @@ __device__ __forceinline__ bool on_a_line_m1(uint32_t a, uint32_t b, uint32_t c)
 }
 
 // ------------------------------------------------------------------------------------------------
-// init kernel: one wavefront per chain.  Seeds the stream (np.random.seed, experiments.py:201/288),
+// init kernel: CI chains per wavefront, L = 64 / CI lanes each.  Seeds the stream (np.random.seed, experiments.py:201/288),
 // builds the initial state (mcmc_board.py:26-59, mcmc.py:20-104), counts E0 and writes the chain
 // record {mt[624], pos, gen_end, E0, state bytes} to the workspace.
-// LDS: mt[624] | state bytes | (full_3d random only) uint16 perm[N^3]
+// Nearly all of it is serial per chain (the seeding recurrence, the sequential draws, the Fisher-Yates swaps), so a wavefront
+// that carried one chain issued every instruction for one useful lane and the kernel was bound by instruction issue: four
+// chains per wavefront (round 3) run the same instruction stream for four chains (65 536 chains of N = 12: board 1.07 ->
+// 0.65 ms; full_3d random, whose Fisher-Yates loop is bound by the LDS round trip per swap and by the chains a CU's LDS holds,
+// 7.8 -> 6.7 ms at two chains per wavefront; profiles/r03_init_kernel.txt).  Chains diverge only inside the rejection loops.
+// LDS per chain (init_words): mt[624] | state bytes | (full_3d random only) uint16 perm[N^3], later the line counters of E0
 // ------------------------------------------------------------------------------------------------
+template <int CI>
 __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     extern __shared__ uint32_t lds[];
-    const long long chain = blockIdx.x;
-    const int lane = threadIdx.x;
+    constexpr int L = 64 / CI;
+    const int lane = threadIdx.x, sub = lane & (L - 1), grp = lane / L;
+    const long long mine = (long long)blockIdx.x * CI + grp;
+    const bool valid = mine < a.n_chains;
+    const long long chain = valid ? mine : a.n_chains - 1;  // (an idle group repeats the last chain in its own LDS slice and writes nothing)
     const int N = a.N, Q = a.Q;
-    uint32_t* mt = lds;
-    uint8_t* st = (uint8_t*)(lds + MT_N);
+    uint32_t* mt = lds + (size_t)grp * a.init_words;
+    uint8_t* st = (uint8_t*)(mt + MT_N);
     uint16_t* perm = (uint16_t*)(st + ((a.state_bytes + 3) & ~3));
+    // any / sum over the L lanes of a chain
+    auto group_any = [&](bool p) { return ((__ballot(p) >> (grp * L)) & (L == 64 ? ~0ull : ((1ull << L) - 1ull))) != 0ull; };
+    auto group_sum = [&](int v) {
+        for (int o = 1; o < L; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
 
     {  // init_genrand: key[p] = s; s = 1812433253 * (s ^ (s >> 30)) + p + 1
         uint32_t s = a.seeds[chain];
         for (int p = 0; p < MT_N; p++) {
-            if (lane == (p & 63)) mt[p] = s;
+            if (sub == (p & (L - 1))) mt[p] = s;
             s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)p + 1u;
         }
     }
     InitRng rng;
-    rng.mt = mt, rng.win = 0, rng.pos = 0, rng.gen_end = 0, rng.lane = lane;  // NumPy's pos == 624: the first draw starts a generation
+    rng.mt = mt, rng.win = 0, rng.pos = 0, rng.gen_end = 0, rng.sub = sub, rng.gbase = lane - sub, rng.L = L;  // NumPy's pos == 624: the first draw starts a generation
     rng.philox = a.rng == MCQ_RNG_PHILOX4X32_10, rng.key = a.seeds[chain];
 
     const unsigned mN = (unsigned)(N - 1);
@@ -379,12 +395,12 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
         if (a.init == MCQ_INIT_RANDOM) {  // N*N sequential draws, row-major
             for (int c = 0; c < Q; c++) {
                 const int h = rng.bounded(mN, a.maskN);
-                if (lane == 0) st[c] = (uint8_t)h;
+                if (sub == 0) st[c] = (uint8_t)h;
             }
         } else if (a.init == MCQ_INIT_LATIN) {
-            for (int c = lane; c < Q; c += 64) st[c] = (uint8_t)((c / N + c % N) % N);
+            for (int c = sub; c < Q; c += L) st[c] = (uint8_t)((c / N + c % N) % N);
         } else if (a.klarner_M == 0) {
-            for (int c = lane; c < Q; c += 64) st[c] = (uint8_t)((3 * (c / N) + 5 * (c % N)) % N);
+            for (int c = sub; c < Q; c += L) st[c] = (uint8_t)((3 * (c / N) + 5 * (c % N)) % N);
         } else {  // Klarner core M x M, the other cells drawn in row-major order
             const int M = a.klarner_M;
             for (int c = 0; c < Q; c++) {
@@ -392,50 +408,52 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
                 int h;
                 if (i < M && j < M) h = (3 * i + 5 * j) % M;
                 else h = rng.bounded(mN, a.maskN);
-                if (lane == 0) st[c] = (uint8_t)h;
+                if (sub == 0) st[c] = (uint8_t)h;
             }
         }
     } else {
         if (a.init == MCQ_INIT_LATIN) {
-            for (int c = lane; c < Q; c += 64) {
+            for (int c = sub; c < Q; c += L) {
                 const int i = c / N, j = c % N;
                 st[3 * c] = (uint8_t)i, st[3 * c + 1] = (uint8_t)j, st[3 * c + 2] = (uint8_t)((i + j) % N);
             }
         } else if (a.init == MCQ_INIT_KLARNER && a.klarner_M == 0) {
-            for (int c = lane; c < Q; c += 64) {
+            for (int c = sub; c < Q; c += L) {
                 const int i = c / N, j = c % N;
                 st[3 * c] = (uint8_t)i, st[3 * c + 1] = (uint8_t)j, st[3 * c + 2] = (uint8_t)((3 * i + 5 * j) % N);
             }
         } else if (a.init == MCQ_INIT_KLARNER) {
             // core in row-major order, then (i,j,k) triples rejected while already used (mcmc.py:63-88)
             const int M = a.klarner_M;
-            for (int c = lane; c < M * M; c += 64) {
+            for (int c = sub; c < M * M; c += L) {
                 const int i = c / M, j = c % M;
                 st[3 * c] = (uint8_t)i, st[3 * c + 1] = (uint8_t)j, st[3 * c + 2] = (uint8_t)((3 * i + 5 * j) % M);
             }
             int n = M * M;
-            while (n < Q) {
-                const int i = rng.bounded(mN, a.maskN);
-                const int j = rng.bounded(mN, a.maskN);
-                const int k = rng.bounded(mN, a.maskN);
-                bool used = false;
-                for (int c = lane; c < n; c += 64) used |= (st[3 * c] == i && st[3 * c + 1] == j && st[3 * c + 2] == k);
-                if (!__any(used)) {
-                    if (lane == 0) st[3 * n] = (uint8_t)i, st[3 * n + 1] = (uint8_t)j, st[3 * n + 2] = (uint8_t)k;
-                    n++;
+            while (__any(n < Q)) {  // (the chains of a wavefront accept at different rates: a chain that is done draws nothing more)
+                if (n < Q) {
+                    const int i = rng.bounded(mN, a.maskN);
+                    const int j = rng.bounded(mN, a.maskN);
+                    const int k = rng.bounded(mN, a.maskN);
+                    bool used = false;
+                    for (int c = sub; c < n; c += L) used |= (st[3 * c] == i && st[3 * c + 1] == j && st[3 * c + 2] == k);
+                    if (!group_any(used)) {
+                        if (sub == 0) st[3 * n] = (uint8_t)i, st[3 * n + 1] = (uint8_t)j, st[3 * n + 2] = (uint8_t)k;
+                        n++;
+                    }
                 }
             }
         } else {
             // np.random.choice(N^3, Q, replace=False) = permutation(N^3)[:Q]: identity array, then for
             // t = n-1 .. 1 swap(arr[t], arr[bounded(t)]) (mcmc.py:97); cells decoded k fastest.
             const int n = N * N * N;
-            for (int t = lane; t < n; t += 64) perm[t] = (uint16_t)t;
+            for (int t = sub; t < n; t += L) perm[t] = (uint16_t)t;
             for (int t = n - 1; t >= 1; t--) {
                 const int s = rng.bounded((unsigned)t, mask_for((unsigned)t));
                 const uint16_t at = perm[t], as = perm[s];
-                if (lane == 0) perm[t] = as, perm[s] = at;
+                if (sub == 0) perm[t] = as, perm[s] = at;
             }
-            for (int c = lane; c < Q; c += 64) {
+            for (int c = sub; c < Q; c += L) {
                 const int f = perm[c];
                 st[3 * c] = (uint8_t)(f / (N * N)), st[3 * c + 1] = (uint8_t)((f / N) % N), st[3 * c + 2] = (uint8_t)(f % N);
             }
@@ -444,61 +462,31 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
 
     // E0 = number of unordered attacking pairs (mcmc_board.py:82-122, mcmc.py:134-169).  Two distinct cells attack iff they
     // share one of the 13 lines through a cell, and no two cells share more than one, so E0 = sum over lines of c (c - 1) / 2
-    // with c the queens on the line: one byte counter per line (c <= N <= 32), O(Q) increments instead of Q^2 / 2 pair tests.
+    // with c the queens on the line: one byte counter per line (c <= N), O(Q) increments instead of Q^2 / 2 pair tests.
     //   N^2 lines each:        (j, k) along i | (i, k) along j | (i, j) along k
     //   N (2N - 1) lines each: (k, i - j), (k, i + j) | (j, i - k), (j, i + k) | (i, j - k), (i, j + k)      planar diagonals
     //   (2N - 1)^2 lines each: (i - j, i - k), (i - j, i + k), (i + j, i - k), (i + j, i + k)                space diagonals
-    // The counters take the place of the permutation array (no longer needed).
+    // One family at a time in a (2N - 1)^2-byte array that takes the place of the permutation array (no longer needed): all 13
+    // at once are 30 N^2 bytes, which keeps a CU to few chains at N = 12 and does not fit at all beyond N = 70.
     int e = 0;
-    if (N <= 32) {
-        uint32_t* cnt = (uint32_t*)perm;
-        const int D = 2 * N - 1, NN = N * N, n_lines = 3 * NN + 6 * N * D + 4 * D * D;
-        for (int w = lane; w < (n_lines + 3) / 4; w += 64) cnt[w] = 0;
-        auto bump = [&](int line) { atomicAdd(&cnt[line >> 2], 1u << (8 * (line & 3))); };
-        for (int c = lane; c < Q; c += 64) {
-            int i, j, k;
-            if (a.mode == MCQ_MODE_BOARD) i = c / N, j = c % N, k = st[c];
-            else i = st[3 * c], j = st[3 * c + 1], k = st[3 * c + 2];
-            const int dij = i - j + N - 1, dik = i - k + N - 1, djk = j - k + N - 1, sij = i + j, sik = i + k, sjk = j + k;
-            int base = 0;
-            bump(base + j * N + k), base += NN;
-            bump(base + i * N + k), base += NN;
-            bump(base + i * N + j), base += NN;
-            bump(base + k * D + dij), base += N * D;
-            bump(base + k * D + sij), base += N * D;
-            bump(base + j * D + dik), base += N * D;
-            bump(base + j * D + sik), base += N * D;
-            bump(base + i * D + djk), base += N * D;
-            bump(base + i * D + sjk), base += N * D;
-            bump(base + dij * D + dik), base += D * D;
-            bump(base + dij * D + sik), base += D * D;
-            bump(base + sij * D + dik), base += D * D;
-            bump(base + sij * D + sik);
-        }
-        for (int w = lane; w < (n_lines + 3) / 4; w += 64) {
-            const uint32_t x = cnt[w];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int c = (int)((x >> (8 * b)) & 0xffu);
-                e += c * (c - 1) / 2;
-            }
-        }
-    } else {
-        // boards beyond N = 32 (MCQ_MAX_N_BOARD): all 13 families at once would not fit the LDS (30 N^2 bytes), so one family at a
-        // time in a (2N - 1)^2-byte array -- the same sum of c (c - 1) / 2 (the k-axis family holds one queen per line on a board)
+    {
         uint32_t* cnt = (uint32_t*)perm;
         const int D = 2 * N - 1, o = N - 1;
+        const bool board = a.mode == MCQ_MODE_BOARD;
         for (int f = 0; f < 13; f++) {
-            if (f == 2) continue;  // lines along k: the column (i, j) itself, one queen each
+            if (f == 2 && board) continue;  // lines along k: on a board the column (i, j) itself, one queen each
             const int lines = f < 3 ? N * N : f < 9 ? N * D : D * D;
-            for (int w = lane; w < (lines + 3) / 4; w += 64) cnt[w] = 0;
+            for (int w = sub; w < (lines + 3) / 4; w += L) cnt[w] = 0;
             __syncthreads();  // (a workgroup of one wavefront: orders the phases for the compiler as well)
-            for (int c = lane; c < Q; c += 64) {
-                const int i = c / N, j = c % N, k = st[c];
+            for (int c = sub; c < Q; c += L) {
+                int i, j, k;
+                if (board) i = c / N, j = c % N, k = st[c];
+                else i = st[3 * c], j = st[3 * c + 1], k = st[3 * c + 2];
                 int line;
                 switch (f) {
                 case 0: line = j * N + k; break;
                 case 1: line = i * N + k; break;
+                case 2: line = i * N + j; break;
                 case 3: line = k * D + (i - j + o); break;
                 case 4: line = k * D + (i + j); break;
                 case 5: line = j * D + (i - k + o); break;
@@ -513,7 +501,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
                 atomicAdd(&cnt[line >> 2], 1u << (8 * (line & 3)));
             }
             __syncthreads();
-            for (int w = lane; w < (lines + 3) / 4; w += 64) {
+            for (int w = sub; w < (lines + 3) / 4; w += L) {
                 const uint32_t x = cnt[w];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
@@ -524,13 +512,14 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
             __syncthreads();
         }
     }
-    e = wave_sum(e);
+    e = group_sum(e);
 
+    if (!valid) return;
     uint32_t* rec = a.ws + chain * (long long)a.rec_words;
-    for (int w = lane; w < MT_N; w += 64) rec[w] = mt[w];
-    if (lane == 0) rec[REC_MIRROR] = mt[0], rec[REC_POS] = (uint32_t)rng.pos, rec[REC_GEN_END] = (uint32_t)rng.gen_end, rec[REC_E0] = (uint32_t)e;
+    for (int w = sub; w < MT_N; w += L) rec[w] = mt[w];
+    if (sub == 0) rec[REC_MIRROR] = mt[0], rec[REC_POS] = (uint32_t)rng.pos, rec[REC_GEN_END] = (uint32_t)rng.gen_end, rec[REC_E0] = (uint32_t)e;
     uint8_t* rst = (uint8_t*)(rec + REC_STATE);
-    for (int c = lane; c < a.state_bytes; c += 64) rst[c] = st[c];
+    for (int c = sub; c < a.state_bytes; c += L) rst[c] = st[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2283,16 +2272,36 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
     if (p->exchange_every > 0)  // 16 doubles at most, from the caller's (host) array
         HIP_TRY(hipMemcpyAsync((void*)a.exch_ladder, p->exchange_ladder, (size_t)p->exchange_replicas * 8, hipMemcpyHostToDevice, s));
+    // init kernel: LDS per chain = the MT19937 words, the state, and behind it the permutation array of np.random.choice (full_3d random
+    // init), later one family of E0 line counters; four chains per wavefront while a CU still holds 8 wavefronts of them, else two or one (full_3d N = 12: 6.7 ms at two, 8.2 ms at four, 7.8 ms at one)
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
-    {  // behind the state: the permutation array of np.random.choice (full_3d random init), then the E0 line counters
-        const size_t D = 2 * (size_t)p->N - 1, lines = p->N <= 32 ? ((3 * (size_t)a.NN + 6 * p->N * D + 4 * D * D + 3) / 4) * 4 : ((D * D + 3) / 4) * 4;  // N > 32: one family of lines at a time
+    {
+        const size_t D = 2 * (size_t)p->N - 1, lines = ((D * D + 3) / 4) * 4;
         bool any_random = p->init == MCQ_INIT_RANDOM;
         for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) any_random |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
         const size_t perm = p->mode == MCQ_MODE_FULL3D && any_random ? (size_t)p->N * p->N * p->N * 2 : 0;
         init_lds += perm > lines ? perm : lines;
+        init_lds = (init_lds + 15) & ~(size_t)15;
     }
     if (init_lds > 160 * 1024) return fail(MCQ_EINVAL, "initial state does not fit in LDS (N^3 permutation array + 3 Q state bytes)");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)init_lds));
+    const int init_ci = 4 * init_lds * 8 <= 160 * 1024 ? 4 : 2 * init_lds * 8 <= 160 * 1024 ? 2 : 1;
+    a.init_words = (int)(init_lds / 4);
+    auto launch_init = [&](const KArgs& k) -> hipError_t {
+        const size_t bytes = (size_t)init_ci * init_lds;
+        const unsigned grid = (unsigned)((k.n_chains + init_ci - 1) / init_ci);
+        hipError_t e;
+        if (init_ci == 4) {
+            e = hipFuncSetAttribute((const void*)mcq_init_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) hipLaunchKernelGGL(mcq_init_kernel<4>, dim3(grid), dim3(64), bytes, s, k);
+        } else if (init_ci == 2) {
+            e = hipFuncSetAttribute((const void*)mcq_init_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) hipLaunchKernelGGL(mcq_init_kernel<2>, dim3(grid), dim3(64), bytes, s, k);
+        } else {
+            e = hipFuncSetAttribute((const void*)mcq_init_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) hipLaunchKernelGGL(mcq_init_kernel<1>, dim3(grid), dim3(64), bytes, s, k);
+        }
+        return e;
+    };
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     if (p->n_steps > 0) {
         for (size_t t = 0; t < n_sets_of(p); t++) {  // one table pair per schedule set
@@ -2310,7 +2319,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         bool mixed = false;
         for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) mixed |= p->sets[t].init_plus1 != 0;
         if (!mixed) {
-            hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->n_chains), dim3(64), init_lds, s, a);
+            HIP_TRY(launch_init(a));
         } else {
             for (size_t t = 0; t < n_sets_of(p); t++) {
                 KArgs b = a;
@@ -2325,7 +2334,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
                 b.seeds = a.seeds + t * (size_t)p->chains_per_set;
                 b.ws = a.ws + t * (size_t)p->chains_per_set * a.rec_words;
                 b.n_chains = p->chains_per_set;
-                hipLaunchKernelGGL(mcq_init_kernel, dim3((unsigned)p->chains_per_set), dim3(64), init_lds, s, b);
+                HIP_TRY(launch_init(b));
             }
         }
     }
