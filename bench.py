@@ -103,6 +103,9 @@ def init_dist(args, torch):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     # one rank per GPU; MCQ_BENCH_BACKEND=gloo (testing only) lets several ranks share a GPU and reduces on the host
     backend = os.environ.get("MCQ_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > max(1, torch.cuda.device_count()):
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} GPU(s) are visible: RCCL runs one rank per GPU "
+                         "(MCQ_BENCH_BACKEND=gloo lets ranks share a GPU and reduces on the host: testing only)")
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
