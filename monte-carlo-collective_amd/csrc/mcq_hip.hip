@@ -999,7 +999,9 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // and for config 5's N = 24 (8 lanes, reduced trace).
 // EXCH: replica exchange between the chains of a ladder (mcq_params.exchange_every > 0; never with PATIENCE or REDUCED).
 // CAND5: board, five candidates for new_k instead of three (N <= 5, where all three equal old_k too often).
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false>
+// EARLYU: the unpacked probe passes (boards beyond N = 16) request their heights together with the old height; for launches that
+// leave the device at most half full (below).
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false>
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
 #endif
@@ -1289,18 +1291,16 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
 
             // packed dE probes: the probed heights depend on (i, j) only; with three passes they are requested together with
             // the old height (with four, the 16 extra live registers would spill)
-            // (Boards beyond N = 16 at 8 lanes -- three unpacked passes -- can do the same, MCQ_EARLY_UNPACKED=1: their twelve byte
-            // reads sit behind the rare-path branch, one LDS round trip later than they have to.  A wavefront alone on its SIMD gains
-            // 7.5 % (N = 24: 14.14 -> 13.08 ms per 20 000 steps), a full device LOSES 3.5 % (config 5 at 8 192 chains per pair: 556 ->
-            // 578 ms; twelve more live registers across the draw) and two wavefronts per SIMD are level: off.  With the reduced trace
-            // the packed variants request early too since round 3: +0.9 % at N = 12.  profiles/r03_early_probes.txt)
-#ifndef MCQ_EARLY_UNPACKED
-#define MCQ_EARLY_UNPACKED 0
-#endif
+            // (Boards beyond N = 16 at 8 lanes -- three unpacked passes -- do the same where it pays, EARLYU: their twelve byte reads
+            // otherwise sit behind the rare-path branch, one LDS round trip later than they have to.  A wavefront alone on its SIMD gains
+            // 7.5 % (N = 24: 14.14 -> 13.08 ms per 20 000 steps), two per SIMD 2.6 % (config 5's per-GPU shape: 89.2 -> 86.9 ms), a full
+            // device LOSES 4 % (552 against 531 ms: twelve more live registers across the draw), so the launcher picks the variant by the
+            // wavefronts the launch puts on a SIMD.  With the reduced trace the packed variants request early too since round 3:
+            // +0.9 % at N = 12.  profiles/r03_early_probes.txt)
 #ifdef MCQ_EXP_NO_EARLY  // timing experiment: no early requests at all
             constexpr bool EARLY_PROBES = false;
 #else
-            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 3 && (PACKED || MCQ_EARLY_UNPACKED != 0);
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 3 && (PACKED || EARLYU);
 #endif
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
@@ -2089,7 +2089,7 @@ int effective_lanes(const mcq_params* p) {
     return G;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -2099,9 +2099,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -2212,12 +2212,18 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 }
         }
         if constexpr (G == 8) {  // larger boards run 8 lanes per chain by default: 3 or 4 straight-line probe passes
-            if (!pat && a.red && a.N == 24) return launch_sweep<MODE, G, false, 3, true, false, 24>(a, s);  // BASELINE config 5: the beta-pair driver's shape (N = 24, reduced trace)
-            if (!pat && a.red && a.N > 16 && a.N <= 24) return launch_sweep<MODE, G, false, 3, true>(a, s);
+            // (a launch that leaves the device at most half full -- two wavefronts per SIMD -- takes the variants that request the probe
+            // heights early: see EARLY_PROBES in the kernel)
+            const bool roomy = (a.n_chains + 7) / 8 <= 2LL * device_simds();
+            if (!pat && a.red && a.N == 24)  // BASELINE config 5: the beta-pair driver's shape (N = 24, reduced trace)
+                return roomy ? launch_sweep<MODE, G, false, 3, true, false, 24, false, false, true>(a, s) : launch_sweep<MODE, G, false, 3, true, false, 24>(a, s);
+            if (!pat && a.red && a.N > 16 && a.N <= 24) return roomy ? launch_sweep<MODE, G, false, 3, true, false, 0, false, false, true>(a, s) : launch_sweep<MODE, G, false, 3, true>(a, s);
             if (!pat && a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, false, 2, true>(a, s);
-            if (!pat && !a.red && a.N > 16 && a.N <= 32) return a.N <= 24 ? launch_sweep<MODE, G, false, 3, false>(a, s) : launch_sweep<MODE, G, false, 4, false>(a, s);
+            if (!pat && !a.red && a.N > 16 && a.N <= 24) return roomy ? launch_sweep<MODE, G, false, 3, false, false, 0, false, false, true>(a, s) : launch_sweep<MODE, G, false, 3, false>(a, s);
+            if (!pat && !a.red && a.N > 24 && a.N <= 32) return launch_sweep<MODE, G, false, 4, false>(a, s);
             if (!pat && !a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, false, 2, false>(a, s);  // N = 9..16: two packed passes
-            if (pat && !a.red && a.N > 16 && a.N <= 32) return a.N <= 24 ? launch_sweep<MODE, G, true, 3, false>(a, s) : launch_sweep<MODE, G, true, 4, false>(a, s);
+            if (pat && !a.red && a.N > 16 && a.N <= 24) return roomy ? launch_sweep<MODE, G, true, 3, false, false, 0, false, false, true>(a, s) : launch_sweep<MODE, G, true, 3, false>(a, s);
+            if (pat && !a.red && a.N > 24 && a.N <= 32) return launch_sweep<MODE, G, true, 4, false>(a, s);
             if (pat && !a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, true, 2, false>(a, s);
         }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);

@@ -50,8 +50,8 @@ def _stopped_hist(hist_len, n_steps, xp, **kw):
 _LONE_MS = {
     2: (11.4, 17.6, 14.6), 3: (11.4, 17.6, 14.6), 4: (9.5, 13.1, 11.8), 5: (11.5, 12.9, 11.9), 6: (11.6, 11.7, 11.0), 7: (10.6, 11.2, 10.6),
     8: (10.1, 10.8, 10.4), 9: (12.6, 11.4, 10.7), 10: (11.9, 10.9, 10.4), 11: (11.6, 10.7, 10.3), 12: (10.9, 10.5, 10.3), 13: (12.4, 10.4, 10.2),
-    14: (12.3, 10.3, 10.1), 15: (12.1, 10.1, 9.9), 16: (12.1, 10.1, 10.0), 17: (17.7, 15.1, 13.2), 18: (17.4, 15.0, 13.0), 19: (17.3, 14.7, 13.0),
-    20: (17.0, 14.5, 16.3), 21: (24.0, 14.4, 16.3), 22: (23.9, 14.4, 16.2), 23: (23.8, 14.2, 16.1), 24: (23.7, 14.2, 16.1),
+    14: (12.3, 10.3, 10.1), 15: (12.1, 10.1, 9.9), 16: (12.1, 10.1, 10.0), 17: (17.7, 14.1, 13.2), 18: (17.4, 13.9, 13.0), 19: (17.3, 13.5, 13.0),
+    20: (17.0, 13.3, 16.3), 21: (24.0, 13.2, 16.3), 22: (23.9, 13.1, 16.2), 23: (23.8, 13.1, 16.1), 24: (23.7, 13.0, 16.1),
 }
 WAVES_PER_SIMD = 4  # resident wavefronts per SIMD of the sweep kernels (their register budget)
 
