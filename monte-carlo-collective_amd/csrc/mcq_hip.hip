@@ -1226,8 +1226,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
             uint32_t uw1 = 0, uw2 = 0;   // the two words of random()
             int stage_no = 0;
             int redraw_from = -1;        // board: words to skip when the word-by-word draw can go on from what the batched attempt established
-            uint32_t seen = 0;           // full_3d: what the batched attempt established (bit 0: the first triple's words are all there, ...)
-            int third_end = 0;           // full_3d: words up to and including the first triple
+            uint32_t seen = 0;           // full_3d: what the batched attempt established (words to skip | stage to go on from << 8; 0: nothing)
             // stream upkeep runs for every chain of the wavefront together (cadence: see LOW_WATER above)
             auto upkeep = [&]() {
                 STAMP(0);
@@ -1422,10 +1421,28 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     const bool second = use2 && (uint32_t)p6 < draw_limit;      // ... and its uniform's words are there
                     pa = use2 ? i2 : pa, pb = use2 ? j2 : pb, pc = use2 ? k2 : pc, pu = second ? p6 : pu;
                     batched = batched || second;
-                    // (what the word-by-word path needs to know should it be taken: see below)
-                    seen = (valid3 ? 1u : 0u) | (valid6 ? 2u : 0u) | (free1 ? 4u : 0u) | (taken2 ? 8u : 0u) | ((uint32_t)(p6 + 1) << 4);
+                    // What the word-by-word path needs to know should it be taken (see below): the words to skip and the stage to go on
+                    // from -- a new triple (1) or, the last triple's cell being free, only the uniform (4).  (valid6 implies valid3.)
+                    const uint32_t skip = (uint32_t)((free1 || !valid6) ? p3 : p6) + 1u;
+                    seen = valid3 ? skip | ((free1 || (valid6 && !taken2)) ? 4u << 8 : 1u << 8) : 0u;
+                    // Both cells taken (Q^2 / N^6 per chain: 5.5 % of the steps of an 8-chain wavefront at N = 12): a third triple, the
+                    // same way, before the chain goes word by word -- that path stalled the wavefront for 6.6 % of config 3's time
+                    // (timing-only build that treats the second cell as free: 62.49 -> 58.37 ms per 20 000 steps).
+                    const bool both = !free1 && valid6 && taken2;
+                    if (wave_any(both)) {
+                        const uint32_t n7 = n6 & (n6 - 1), n8 = n7 & (n7 - 1), n9 = n8 & (n8 - 1);
+                        const int p7 = lowest_bit(n7), p8 = lowest_bit(n8), p9 = lowest_bit(n9 & 0x3fffffffu);
+                        const uint32_t w7 = rs[p7], w8 = rs[p8], w9 = rs[p9];
+                        const int i3 = (int)(w7 & maskN), j3 = (int)(w8 & maskN), k3 = (int)(w9 & maskN) & 31;
+                        const uint32_t cw3 = colw[__mul24(i3, N) + j3];
+                        const bool look3 = both && (uint32_t)p9 < availm, taken3 = ((cw3 >> k3) & 1u) != 0;
+                        const bool use3 = look3 && !taken3;
+                        const bool third_ok = use3 && (uint32_t)p9 < draw_limit;
+                        pa = use3 ? i3 : pa, pb = use3 ? j3 : pb, pc = use3 ? k3 : pc, pu = third_ok ? p9 : pu;
+                        batched = batched || third_ok;
+                        seen = look3 ? ((uint32_t)p9 + 1u) | (taken3 ? 1u << 8 : 4u << 8) : seen;
+                    }
                 }
-                third_end = p3 + 1;
                 uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
                 rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
@@ -1441,13 +1458,12 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                             rng.consume((uint32_t)redraw_from);
                             stage_no = 2;
                         }
-                    } else if (seen & 1u) {
-                        // Both cells taken (Q^2 / N^6 per chain: 5.5 % of the steps of an 8-chain wavefront at N = 12), or the ring
-                        // short: q and the triples whose words are all there stand.  The draw goes on behind the last of them --
-                        // with a new triple (stage 1) or, its cell being free, only the uniform (stage 4) -- instead of starting over.
-                        const bool valid6 = (seen & 2u) != 0, free1 = (seen & 4u) != 0, taken2 = (seen & 8u) != 0;
-                        rng.consume((uint32_t)((free1 || !valid6) ? third_end : (int)(seen >> 4)));
-                        stage_no = (free1 || (valid6 && !taken2)) ? 4 : 1;
+                    } else if (seen) {
+                        // The cells of the batched triples are all taken, or the ring was short: q and the triples whose words are all
+                        // there stand.  The draw goes on behind the last of them -- with a new triple (stage 1) or, its cell being free,
+                        // only the uniform (stage 4) -- instead of starting over.
+                        rng.consume(seen & 0xffu);
+                        stage_no = (int)(seen >> 8);
                     }
                     sequential();
                     if constexpr (EARLY_PROBES) load_probes();
