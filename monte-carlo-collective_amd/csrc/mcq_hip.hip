@@ -1421,6 +1421,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     const bool second = use2 && (uint32_t)p6 < draw_limit;      // ... and its uniform's words are there
                     pa = use2 ? i2 : pa, pb = use2 ? j2 : pb, pc = use2 ? k2 : pc, pu = second ? p6 : pu;
                     batched = batched || second;
+                    if (wave_any(!batched)) {  // (one time in nine: some chain's second cell is taken too, or its ring is short)
                     // What the word-by-word path needs to know should it be taken (see below): the words to skip and the stage to go on
                     // from -- a new triple (1) or, the last triple's cell being free, only the uniform (4).  (valid6 implies valid3.)
                     const uint32_t skip = (uint32_t)((free1 || !valid6) ? p3 : p6) + 1u;
@@ -1441,6 +1442,7 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                         pa = use3 ? i3 : pa, pb = use3 ? j3 : pb, pc = use3 ? k3 : pc, pu = third_ok ? p9 : pu;
                         batched = batched || third_ok;
                         seen = look3 ? ((uint32_t)p9 + 1u) | (taken3 ? 1u << 8 : 4u << 8) : seen;
+                    }
                     }
                 }
                 uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
