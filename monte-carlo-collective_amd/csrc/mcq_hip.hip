@@ -560,11 +560,11 @@ __device__ __forceinline__ uint32_t pk_star2(uint32_t bb, uint32_t dd) {
     return bb | __builtin_bit_cast(uint32_t, l) | __builtin_bit_cast(uint32_t, r);
 }
 
-// DPP reductions over the G lanes of a group (G = 4, 8 or 16), result in every lane of the group.
+// DPP reductions over the G lanes of a group (G = 2, 4, 8 or 16), result in every lane of the group.
 template <int G>
 __device__ __forceinline__ int group_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);                // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);                // quad_perm [2,3,0,1]
+    if (G >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
     if (G >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
     if (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
     return v;
@@ -573,7 +573,7 @@ template <int G>
 __device__ __forceinline__ uint32_t group_or(uint32_t u) {
     int v = (int)u;
     v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    if (G >= 4) v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
     if (G >= 8) v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
     if (G >= 16) v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
     return (uint32_t)v;
@@ -642,6 +642,14 @@ struct Stream {
         if (HASQ) okq |= (uint64_t)bitsq16 << rel;
     }
 
+    // randint(0, N) accept flags of four words (bit w: word w passes): the low bytes side by side; per byte
+    // (0x80 + N - 1) - (t & maskN) keeps bit 7 iff the word passes; a dot product with (1, 2, 4, 8) collects the four flags
+    __device__ __forceinline__ uint32_t flags4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) const {
+        const uint32_t b01 = __builtin_amdgcn_perm(t1, t0, 0x0c0c0400u), b23 = __builtin_amdgcn_perm(t3, t2, 0x04000c0cu);
+        const uint32_t d = okK4 - ((b01 | b23) & okM4);
+        return __builtin_amdgcn_udot4((d >> 7) & 0x01010101u, 0x08040201u, 0u, false);
+    }
+
     // MT word `idx` of this chain: uniform base + 32-bit offset, so the address needs no 64-bit vector math
     __device__ __forceinline__ uint32_t* word(int idx) const { return (uint32_t*)(wbase + (coff + 4u * (uint32_t)idx)); }
     // Timing experiments (tools/exp_build.sh; never defined in the shipped library, results are wrong with any of them):
@@ -666,7 +674,15 @@ struct Stream {
         struct __attribute__((packed, aligned(4))) W2 { uint32_t x, y; };
         const int i0 = gi + gl * WPL;
         const int ix0 = i0 + MT_M >= MT_N ? i0 + MT_M - MT_N : i0 + MT_M;
-        if constexpr (WPL == 4) {
+        if constexpr (WPL == 8) {
+            // two runs of four: each half of (i+397) mod 624 wraps on its own (the first can run over the end by the one mirrored
+            // word, at i0 = 224; the second then starts at word 1)
+            const int ix1 = i0 + 4 + MT_M >= MT_N ? i0 + 4 + MT_M - MT_N : i0 + 4 + MT_M;
+            const uint4 q0 = *(const uint4*)lword(i0), q1 = *(const uint4*)lword(i0 + 4);
+            pa[0] = q0.x, pa[1] = q0.y, pa[2] = q0.z, pa[3] = q0.w, pa[4] = q1.x, pa[5] = q1.y, pa[6] = q1.z, pa[7] = q1.w;
+            const W4 x0 = *(const W4*)lword(ix0), x1 = *(const W4*)lword(ix1);
+            px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
+        } else if constexpr (WPL == 4) {
             const uint4 q = *(const uint4*)lword(i0);
             pa[0] = q.x, pa[1] = q.y, pa[2] = q.z, pa[3] = q.w;
 #ifdef MCQ_EXP_NT_XLOAD
@@ -696,7 +712,11 @@ struct Stream {
         uint32_t o[4], t[WPL];
         const uint32_t blk = (gen >> 2) | (gen_hi << 30);  // gen is a multiple of 16: the low two bits of blk are free for the lane's part
         philox4x32_10(blk | ((uint32_t)(gl * WPL) >> 2), gen_hi >> 2, pkey, o);
-        if constexpr (WPL == 4) {
+        if constexpr (WPL == 8) {  // two blocks per lane
+            t[0] = o[0], t[1] = o[1], t[2] = o[2], t[3] = o[3];
+            philox4x32_10(blk | (((uint32_t)(gl * WPL) >> 2) + 1u), gen_hi >> 2, pkey, o);
+            t[4] = o[0], t[5] = o[1], t[6] = o[2], t[7] = o[3];
+        } else if constexpr (WPL == 4) {
             t[0] = o[0], t[1] = o[1], t[2] = o[2], t[3] = o[3];
         } else if constexpr (WPL == 2) {
             t[0] = (gl & 1) ? o[2] : o[0], t[1] = (gl & 1) ? o[3] : o[1];
@@ -713,12 +733,14 @@ struct Stream {
         uint32_t bits = 0, bitsq = 0;
         uint32_t* slot = ring + so + gl * WPL;
         uint32_t* mirror = ring + (so < RING_MIRROR ? so + RING : so) + gl * WPL;  // mirror of slots 0..31 (otherwise the same store again)
-        if constexpr (WPL == 4) {
+        if constexpr (WPL == 8) {
+            *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(slot + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(mirror + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            bits = (flags4(t[0], t[1], t[2], t[3]) | (flags4(t[4], t[5], t[6], t[7]) << 4)) << (gl * 8);
+        } else if constexpr (WPL == 4) {
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
             *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
-            const uint32_t b01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x04000c0cu);
-            const uint32_t d = okK4 - ((b01 | b23) & okM4);
-            bits = __builtin_amdgcn_udot4((d >> 7) & 0x01010101u, 0x08040201u, 0u, false) << (gl * 4);
+            bits = flags4(t[0], t[1], t[2], t[3]) << (gl * 4);
         } else {
 #pragma unroll
             for (int w = 0; w < WPL; w++) {
@@ -749,7 +771,12 @@ struct Stream {
         }
         uint32_t* slot = ring + so + gl * WPL;
         uint32_t* mirror = ring + (so < RING_MIRROR ? so + RING : so) + gl * WPL;  // mirror of slots 0..31 (otherwise the same store again)
-        if constexpr (WPL == 4) {
+        if constexpr (WPL == 8) {
+            *(uint4*)sword(i0) = make_uint4(v[0], v[1], v[2], v[3]), *(uint4*)sword(i0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+            *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(slot + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(mirror + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            bits = (flags4(t[0], t[1], t[2], t[3]) | (flags4(t[4], t[5], t[6], t[7]) << 4)) << (gl * 8);
+        } else if constexpr (WPL == 4) {
 #if defined(MCQ_EXP_NO_STORE)
 #elif defined(MCQ_EXP_NT_STORE)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -765,11 +792,7 @@ struct Stream {
 #endif
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
             *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
-            // the low bytes of the four words side by side; per byte (0x80 + N - 1) - (t & maskN) keeps bit 7 iff the
-            // word passes; a dot product with (1, 2, 4, 8) collects the four flags
-            const uint32_t b01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x04000c0cu);
-            const uint32_t d = okK4 - ((b01 | b23) & okM4);
-            bits = __builtin_amdgcn_udot4((d >> 7) & 0x01010101u, 0x08040201u, 0u, false) << (gl * 4);
+            bits = flags4(t[0], t[1], t[2], t[3]) << (gl * 4);
         } else {
             if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
             else *word(i0) = v[0];
@@ -1005,7 +1028,12 @@ template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = fa
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
 #endif
-__global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
+// (G = 2: 32 chains per wavefront take twice the LDS of 16, so a CU holds two of those wavefronts per SIMD, and each may use the registers of two)
+#ifndef MCQ_G2_WAVES
+#define MCQ_G2_WAVES 2
+#endif
+__global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
+    static_assert(G >= 4 || MODE == MCQ_MODE_BOARD, "two lanes per chain: boards only (full_3d splits a chain's lanes between two cells)");
     static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
     WAVE_T0;
     // where this wavefront runs: HW_ID = wave slot [3:0], SIMD [5:4], CU [11:8], SE [14:13]; XCC_ID [3:0]
@@ -1299,7 +1327,10 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
 #ifdef MCQ_EXP_NO_EARLY  // timing experiment: no early requests at all
             constexpr bool EARLY_PROBES = false;
 #else
-            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= 3 && (PACKED || EARLYU);
+#ifndef MCQ_G2_EARLY_NT  // (two lanes per chain: the register budget of two wavefronts per SIMD holds the probed heights of up to eight passes)
+#define MCQ_G2_EARLY_NT 8
+#endif
+            constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= (G == 2 ? MCQ_G2_EARLY_NT : 3) && (PACKED || EARLYU);
 #endif
             uint32_t ph[4 * NTP];
             auto load_probes = [&]() {
@@ -1693,7 +1724,10 @@ __global__ __launch_bounds__(64, (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ?
                     // lines out of the L2 (reads 68.0 -> 65.6 B/move, time unchanged; profiles/r02_nt_trace_experiment.txt)
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    if constexpr (WPL == 4) __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
+                    if constexpr (WPL == 8) {
+                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 8), (u32x4*)hist_at(e - 15));
+                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 8 + 4), (u32x4*)hist_at(e - 15) + 1);
+                    } else if constexpr (WPL == 4) __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
                     else if constexpr (WPL == 2) __builtin_nontemporal_store(*(const u32x2*)(stage + gl * 2), (u32x2*)hist_at(e - 15));
                     else __builtin_nontemporal_store((int)stage[gl], hist_at(e - 15));
                 }
@@ -1959,8 +1993,13 @@ int validate(const mcq_params* p) {
     if (p->n_steps < 0 || p->n_steps > 2147483000LL) return fail(MCQ_EINVAL, "n_steps out of range [0, 2^31)");
     if (p->n_chains < 0) return fail(MCQ_EINVAL, "negative n_chains");
     if (p->n_chains > 2147483647LL) return fail(MCQ_EINVAL, "n_chains out of range [0, 2^31)");  // one workgroup per chain in the init kernel
-    if (p->lanes_per_chain != 0 && p->lanes_per_chain != 4 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
-        return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 4, 8 or 16");
+    if (p->lanes_per_chain != 0 && p->lanes_per_chain != 2 && p->lanes_per_chain != 4 && p->lanes_per_chain != 8 && p->lanes_per_chain != 16)
+        return fail(MCQ_EINVAL, "lanes_per_chain must be 0, 2, 4, 8 or 16");
+    if (p->lanes_per_chain == 2) {  // 32 chains per wavefront
+        if (p->mode != MCQ_MODE_BOARD) return fail(MCQ_EINVAL, "lanes_per_chain 2 applies to mcmc_type board (full_3d splits a chain's lanes between the old and the new cell)");
+        if (p->n_sets > 1 && p->chains_per_set % 32 != 0) return fail(MCQ_EINVAL, "lanes_per_chain 2 needs chains_per_set to be a multiple of 32 (a wavefront belongs to one set)");
+        if (p->trace == MCQ_TRACE_I32 && p->bits_stride >= (1LL << 23)) return fail(MCQ_EINVAL, "lanes_per_chain 2 needs bits_stride < 2^23");
+    }
     if (p->n_sets < 0) return fail(MCQ_EINVAL, "negative n_sets");
     if (p->n_sets > 1) {
         if (!p->sets) return fail(MCQ_EINVAL, "n_sets > 1 without sets");
@@ -2202,6 +2241,12 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     } else {
         const bool pat = a.patience >= 0 && a.patience <= a.n_steps;  // a patience beyond n_steps can never stop a chain: the plain variants give the same results
+        if constexpr (G == 2) {  // 32 chains per wavefront, ceil(N / 2) packed probe passes: the size of BASELINE config 2
+            if (a.N == 12) {
+                if (!pat) return a.red ? launch_sweep<MODE, G, false, 6, true, false, 12>(a, s) : launch_sweep<MODE, G, false, 6, false, false, 12>(a, s);
+                if (!a.red) return launch_sweep<MODE, G, true, 6, false, false, 12>(a, s);
+            }
+        }
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
             // (early stopping -- the reference's default early_stop_patience = 100000 -- has its own unrolled variants for the
             // sizes that default to 4 lanes)
@@ -2251,6 +2296,10 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
 
 template <int MODE>
 int launch_sweep_mode(const KArgs& a, int G, hipStream_t s) {
+    if (G == 2) {
+        if constexpr (MODE == MCQ_MODE_BOARD) return launch_sweep_g<MODE, 2>(a, s);
+        else return fail(MCQ_EINVAL, "lanes_per_chain 2 applies to mcmc_type board");
+    }
     if (G == 4) return launch_sweep_g<MODE, 4>(a, s);
     if (G == 8) return launch_sweep_g<MODE, 8>(a, s);
     return launch_sweep_g<MODE, 16>(a, s);
