@@ -152,6 +152,8 @@ struct KArgs {
     int low_water;            // stream upkeep runs when some chain of the wavefront holds fewer ready words than this
     int init_words;           // init kernel: LDS words per chain
     const double* exch_ladder;  // [exch_R] beta multipliers per rung (workspace)
+    uint16_t* qtab;           // full_3d: the queens of every chain as i | j << 5 | k << 10, [n_chains][qtab_stride] (workspace; the sweep variants that
+    int qtab_stride;          // keep their queen table out of LDS work on it, the init kernel fills it)
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -520,6 +522,10 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     if (sub == 0) rec[REC_MIRROR] = mt[0], rec[REC_POS] = (uint32_t)rng.pos, rec[REC_GEN_END] = (uint32_t)rng.gen_end, rec[REC_E0] = (uint32_t)e;
     uint8_t* rst = (uint8_t*)(rec + REC_STATE);
     for (int c = sub; c < a.state_bytes; c += L) rst[c] = st[c];
+    if (a.mode == MCQ_MODE_FULL3D && a.qtab) {
+        uint16_t* qt = a.qtab + chain * (long long)a.qtab_stride;
+        for (int c = sub; c < Q; c += L) qt[c] = (uint16_t)(st[3 * c] | (st[3 * c + 1] << 5) | (st[3 * c + 2] << 10));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,7 +599,8 @@ __device__ __forceinline__ uint32_t group_or(uint32_t u) {
 //
 // PHILOX (mcq_params.rng == MCQ_RNG_PHILOX4X32_10): the same ring, but a block of 16 words is computed from the chain's
 // word counter (`generate`) instead of being regenerated from a state in memory: no issue / complete, no record traffic.
-template <int G, bool HASQ, bool PHILOX = false>
+// MIRROR = false: a ring without the mirrored slots (readers wrap their slot indices themselves): 128 bytes of LDS per chain less.
+template <int G, bool HASQ, bool PHILOX = false, bool MIRROR = true>
 struct Stream {
     static constexpr int WPL = 16 / G;  // words per lane in a block
     char* wbase;    // wave-uniform: record of the wavefront's first chain (kept in scalar registers)
@@ -735,16 +742,17 @@ struct Stream {
         uint32_t* mirror = ring + (so < RING_MIRROR ? so + RING : so) + gl * WPL;  // mirror of slots 0..31 (otherwise the same store again)
         if constexpr (WPL == 8) {
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(slot + 4) = make_uint4(t[4], t[5], t[6], t[7]);
-            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(mirror + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            if constexpr (MIRROR) *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(mirror + 4) = make_uint4(t[4], t[5], t[6], t[7]);
             bits = (flags4(t[0], t[1], t[2], t[3]) | (flags4(t[4], t[5], t[6], t[7]) << 4)) << (gl * 8);
         } else if constexpr (WPL == 4) {
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
-            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
+            if constexpr (MIRROR) *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
             bits = flags4(t[0], t[1], t[2], t[3]) << (gl * 4);
         } else {
 #pragma unroll
             for (int w = 0; w < WPL; w++) {
-                slot[w] = t[w], mirror[w] = t[w];
+                slot[w] = t[w];
+                if constexpr (MIRROR) mirror[w] = t[w];
                 bits |= ((t[w] & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
             }
         }
@@ -774,7 +782,7 @@ struct Stream {
         if constexpr (WPL == 8) {
             *(uint4*)sword(i0) = make_uint4(v[0], v[1], v[2], v[3]), *(uint4*)sword(i0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(slot + 4) = make_uint4(t[4], t[5], t[6], t[7]);
-            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(mirror + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            if constexpr (MIRROR) *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]), *(uint4*)(mirror + 4) = make_uint4(t[4], t[5], t[6], t[7]);
             bits = (flags4(t[0], t[1], t[2], t[3]) | (flags4(t[4], t[5], t[6], t[7]) << 4)) << (gl * 8);
         } else if constexpr (WPL == 4) {
 #if defined(MCQ_EXP_NO_STORE)
@@ -791,14 +799,15 @@ struct Stream {
             *(uint4*)sword(i0) = make_uint4(v[0], v[1], v[2], v[3]);
 #endif
             *(uint4*)slot = make_uint4(t[0], t[1], t[2], t[3]);
-            *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
+            if constexpr (MIRROR) *(uint4*)mirror = make_uint4(t[0], t[1], t[2], t[3]);
             bits = flags4(t[0], t[1], t[2], t[3]) << (gl * 4);
         } else {
             if constexpr (WPL == 2) *(uint2*)word(i0) = make_uint2(v[0], v[1]);
             else *word(i0) = v[0];
 #pragma unroll
             for (int w = 0; w < WPL; w++) {
-                slot[w] = t[w], mirror[w] = t[w];
+                slot[w] = t[w];
+                if constexpr (MIRROR) mirror[w] = t[w];
                 bits |= ((t[w] & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
             }
         }
@@ -850,7 +859,7 @@ struct Stream {
                 if (t >= rpos && t < rge) {
                     const uint32_t x = temper(*word(t));
                     ring[t & (RING - 1)] = x;
-                    if ((t & (RING - 1)) < RING_MIRROR) ring[(t & (RING - 1)) + RING] = x;
+                    if (MIRROR && (t & (RING - 1)) < RING_MIRROR) ring[(t & (RING - 1)) + RING] = x;
                     bits |= ((x & maskN) <= mN ? 1u : 0u) << (gl * WPL + w);
                     bitsq |= ((x & maskQ) <= mQ ? 1u : 0u) << (gl * WPL + w);
                 }
@@ -1024,7 +1033,11 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // CAND5: board, five candidates for new_k instead of three (N <= 5, where all three equal old_k too often).
 // EARLYU: the unpacked probe passes (boards beyond N = 16) request their heights together with the old height; for launches that
 // leave the device at most half full (below).
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false>
+// SLIM (full_3d, unrolled 16-bit column words): the layout that lets BASELINE configs[2]'s 65 536 chains of N = 12 run at 4 lanes per chain in ONE
+// resident round (16 chains per wavefront x 16 wavefronts per CU need <= 640 B of LDS per chain): the queen table lives in global memory
+// (KArgs::qtab: one 2-byte read per step once q is known, one write per accepted move), the ring has no mirror (readers wrap their
+// slot indices) and the history is staged 8 entries at a time: stage[8] | cold[4] | ring[64] | column words.
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false>
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
 #endif
@@ -1032,7 +1045,8 @@ template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = fa
 #ifndef MCQ_G2_WAVES
 #define MCQ_G2_WAVES 2
 #endif
-__global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
+__global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0 && !SLIM) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
+    static_assert(!SLIM || (MODE == MCQ_MODE_FULL3D && NT > 0 && !REDUCED && !PATIENCE), "the slim layout exists for the unrolled full_3d kernels with a full (or no) trace");
     static_assert(G >= 4 || MODE == MCQ_MODE_BOARD, "two lanes per chain: boards only (full_3d splits a chain's lanes between two cells)");
     static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
     WAVE_T0;
@@ -1042,7 +1056,11 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     uint32_t* pace_row = a.pace + 16u * (((xcc_id & 7u) << 8) | (((hw_id >> 13) & 3u) << 6) | (((hw_id >> 8) & 15u) << 2) | ((hw_id >> 4) & 3u));
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
-    constexpr int WPL = 16 / G;
+    constexpr int SB = SLIM ? 8 : 16;  // history entries staged per chain between two flushes
+    constexpr int WPL = SB / G;        // ... and how many of them a lane stores in a flush
+    // LDS slice of a chain (word offsets): stage[SB] | cold[4] | ring[64 (+ 32 mirrored)] | state
+    constexpr int L_STAGE = 0, L_COLD = SB, L_RING = SB + 4, L_STATE = L_RING + RING + (SLIM ? 0 : RING_MIRROR);
+    static_assert(SLIM || (L_STAGE == LDS_STAGE && L_COLD == LDS_COLD && L_RING == LDS_RING && L_STATE == LDS_STATE), "layout constants");
     constexpr int LAST = MODE == MCQ_MODE_BOARD ? 5 : 6;  // sequential-draw stages of one proposal
     const int lane = threadIdx.x;
     const int gl = lane & (G - 1), grp = lane / G;
@@ -1056,17 +1074,20 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     const long long crow = active ? chain : 0;
 
     uint32_t* base = lds + grp * a.chain_lds_words;
-    uint32_t* ring = base + LDS_RING;
-    uint32_t* stage = base + LDS_STAGE;
+    uint32_t* ring = base + L_RING;
+    uint32_t* stage = base + L_STAGE;
     // board: the diagonal probes read (and discard) up to N-1 bytes outside either end of the heights: in front of them lies the
     // ring's mirror, behind them (N+2)/4 spare words -- both the chain's own
-    uint8_t* hts = (uint8_t*)(base + LDS_STATE);
+    uint8_t* hts = (uint8_t*)(base + L_STATE);
     // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
     // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
     constexpr bool NARROW = MODE == MCQ_MODE_FULL3D && NT > 0;  // N <= 16: 16-bit column words
     typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type colw_t;
-    colw_t* colw = (colw_t*)(base + LDS_STATE) + full_pad;
-    uint16_t* qn = (uint16_t*)(colw + NN + full_pad);
+    colw_t* colw = (colw_t*)(base + L_STATE) + full_pad;
+    uint16_t* const qn = [&]() {
+        if constexpr (SLIM) return a.qtab + crow * (long long)a.qtab_stride;  // global memory, filled by the init kernel
+        else return (uint16_t*)(colw + NN + full_pad);
+    }();
 
     // ---- load the chain record ----
     uint32_t* rec = a.ws + crow * (long long)a.rec_words;
@@ -1074,12 +1095,12 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     if (MODE == MCQ_MODE_BOARD) {
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
     } else {
-        uint32_t* cw32 = base + LDS_STATE;  // the column table and its pads as 32-bit words
+        uint32_t* cw32 = base + L_STATE;  // the column table and its pads as 32-bit words
         const int cwords = (int)((2 * full_pad + NN) * sizeof(colw_t) / 4);
         for (int w = gl; w < cwords; w += G) cw32[w] = 0;
         for (int c = gl; c < Q; c += G) {
             const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
-            qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
+            if constexpr (!SLIM) qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
             const uint32_t e = (uint32_t)full_pad + qi_ * N + qj_;  // element index from the start of the table
             if (NARROW) atomicOr(&cw32[e >> 1], (1u << qk_) << ((e & 1u) * 16u));
             else atomicOr(&cw32[e], 1u << qk_);
@@ -1091,7 +1112,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     asm volatile("" : "+s"(tc1), "+s"(tc2));  // opaque scalars: no literal operands in the tempering
     const uint32_t rec_bytes = (uint32_t)a.rec_words * 4u;
     char* wave_base = (char*)(a.ws + (long long)blockIdx.x * CPW * (long long)a.rec_words);
-    Stream<G, MODE == MCQ_MODE_FULL3D, PHILOX> rng;
+    Stream<G, MODE == MCQ_MODE_FULL3D, PHILOX, !SLIM> rng;
     rng.attach(wave_base, active ? (uint32_t)grp * rec_bytes : 0u, ring, (int)rec[REC_POS], (int)rec[REC_GEN_END], gl, maskN, mN, maskQ, mQ, tc1, tc2);
     if constexpr (PHILOX) rng.attach_philox(a.seeds[crow], rec[REC_POS]);
 
@@ -1099,7 +1120,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     int best = E;
     // steps_to_best, n_accepted, near ties and the history length change rarely: they live in LDS, not in registers (every lane of
     // a group performs the same read-modify-write in lockstep)
-    int* cold = (int*)(base + LDS_COLD);
+    int* cold = (int*)(base + L_COLD);
     enum { C_BEST_STEP = 0, C_N_ACC = 1, C_TIES = 2, C_HIST_LEN = 3 };
     cold[C_BEST_STEP] = 0, cold[C_N_ACC] = 0, cold[C_TIES] = 0, cold[C_HIST_LEN] = active ? (int)a.n_steps + 1 : 0;
     unsigned long long* red = reduced ? a.red + (a.chains_per_set > 0 ? ((long long)blockIdx.x * CPW) / a.chains_per_set : 0) * a.red_set_stride +
@@ -1118,7 +1139,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     uint32_t batch_mask = force_slow ? 0u : 0xffffffffu;  // wave-uniform
     asm volatile("" : "+s"(batch_mask));
     const bool trace = a.out.energy_hist != nullptr;
-    int flush_at = trace ? 15 : 99;
+    int flush_at = trace ? SB - 1 : 99;
     asm volatile("" : "+s"(flush_at));  // an opaque scalar: one compare per step, whatever the compiler could derive from the 99
     // trace rows: wave-uniform address of the wavefront's first row (scalar registers) + a 32-bit byte offset per lane, so that no
     // 64-bit pointer is held in vector registers (16 rows of hist_stride < 2^24 entries span < 2^30 bytes: checked by the host side)
@@ -1420,10 +1441,14 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 // the third word must leave its two followers (the uniform's) inside the view: positions 0..29 (none there: p3 = -1)
                 const int p1 = lowest_bit(n1), p2 = lowest_bit(n2), p3 = lowest_bit(n3 & 0x3fffffffu);
                 const uint32_t draw_limit = (avail - 2u) & batch_mask;  // p + 2 < avail as p < draw_limit (see the board branch)
-                // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring
+                // no wrap-around: s <= 63 and every position is <= 31, inside the mirrored ring (SLIM: no mirror, the slot index wraps)
                 const uint32_t* rs = ring + s;
-                const uint32_t wq = rs[pq];
-                const uint32_t w1 = rs[p1], w2 = rs[p2], w3 = rs[p3];
+                auto rd = [&](int p) __attribute__((always_inline)) -> uint32_t {
+                    if constexpr (SLIM) return ring[(s + (uint32_t)p) & (RING - 1)];
+                    else return rs[p];
+                };
+                const uint32_t wq = rd(pq);
+                const uint32_t w1 = rd(p1), w2 = rd(p2), w3 = rd(p3);
                 if (upkeep_now) upkeep();  // while those reads are in flight
                 const uint32_t vqi = wq & maskQ;
                 qi = (int)min(vqi, mQ);  // (a used attempt has vqi <= mQ; an unused one must still index inside the queen table)
@@ -1442,7 +1467,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     STAMP_COUNT(10);
                     const uint32_t n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                     const int p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6 & 0x3fffffffu);
-                    const uint32_t w4 = rs[p4], w5 = rs[p5], w6 = rs[p6];
+                    const uint32_t w4 = rd(p4), w5 = rd(p5), w6 = rd(p6);
                     const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
                     const uint32_t cw2 = colw[__mul24(i2, N) + j2];
                     // (a position counts only when its word has been generated; nothing does under MCQ_FLAG_SEQUENTIAL_DRAWS)
@@ -1464,7 +1489,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     if (wave_any(both)) {
                         const uint32_t n7 = n6 & (n6 - 1), n8 = n7 & (n7 - 1), n9 = n8 & (n8 - 1);
                         const int p7 = lowest_bit(n7), p8 = lowest_bit(n8), p9 = lowest_bit(n9 & 0x3fffffffu);
-                        const uint32_t w7 = rs[p7], w8 = rs[p8], w9 = rs[p9];
+                        const uint32_t w7 = rd(p7), w8 = rd(p8), w9 = rd(p9);
                         const int i3 = (int)(w7 & maskN), j3 = (int)(w8 & maskN), k3 = (int)(w9 & maskN) & 31;
                         const uint32_t cw3 = colw[__mul24(i3, N) + j3];
                         const bool look3 = both && (uint32_t)p9 < availm, taken3 = ((cw3 >> k3) & 1u) != 0;
@@ -1476,7 +1501,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     }
                     }
                 }
-                uw1 = rs[pu + 1], uw2 = rs[pu + 2];  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
+                uw1 = rd(pu + 1), uw2 = rd(pu + 2);  // the uniform's words follow the chosen triple (pu >= -1: inside the chain's ring)
                 rng.consume(batched ? (uint32_t)pu + 3u : 0u);
             }
             STAMP_COUNT(7);  // (diagnostic build: wavefront-steps, and those of them that take the word-by-word path)
@@ -1718,18 +1743,18 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
 
             // the common tail of a step: append the entry, flush full blocks, pace
             auto append_entry = [&]() {
-                stage[e & 15] = (uint32_t)E | (reduced ? 0x40000000u | (acc << 31) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
-                if ((e & 15) == flush_at) {  // one aligned 64-byte segment per chain (flush_at = 15, or out of reach without a trace)
+                stage[e & (SB - 1)] = (uint32_t)E | (reduced ? 0x40000000u | (acc << 31) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
+                if ((e & (SB - 1)) == flush_at) {  // one aligned 64-byte segment per chain, 32-byte with SLIM (flush_at = SB - 1, or out of reach without a trace)
                     // non-temporal: the trace is written once and never read here, so its lines should not push the MT19937 state's
                     // lines out of the L2 (reads 68.0 -> 65.6 B/move, time unchanged; profiles/r02_nt_trace_experiment.txt)
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                     if constexpr (WPL == 8) {
-                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 8), (u32x4*)hist_at(e - 15));
-                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 8 + 4), (u32x4*)hist_at(e - 15) + 1);
-                    } else if constexpr (WPL == 4) __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - 15));
-                    else if constexpr (WPL == 2) __builtin_nontemporal_store(*(const u32x2*)(stage + gl * 2), (u32x2*)hist_at(e - 15));
-                    else __builtin_nontemporal_store((int)stage[gl], hist_at(e - 15));
+                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 8), (u32x4*)hist_at(e - (SB - 1)));
+                        __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 8 + 4), (u32x4*)hist_at(e - (SB - 1)) + 1);
+                    } else if constexpr (WPL == 4) __builtin_nontemporal_store(*(const u32x4*)(stage + gl * 4), (u32x4*)hist_at(e - (SB - 1)));
+                    else if constexpr (WPL == 2) __builtin_nontemporal_store(*(const u32x2*)(stage + gl * 2), (u32x2*)hist_at(e - (SB - 1)));
+                    else __builtin_nontemporal_store((int)stage[gl], hist_at(e - (SB - 1)));
                 }
                 if ((e & 31) == 0) {
                     cold[C_N_ACC] += __popc(accw);  // accepted moves are counted from the bit words
@@ -1761,11 +1786,11 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                         if constexpr (REDUCED) {  // this step counts as executed / accepted but appends no entry; the rest of the block is stale
 #pragma unroll
                             for (int w = 0; w < WPL; w++)
-                                if (gl * WPL + w >= (e & 15)) stage[gl * WPL + w] = gl * WPL + w == (e & 15) && acc ? 0x80000000u : 0u;
+                                if (gl * WPL + w >= (e & (SB - 1))) stage[gl * WPL + w] = gl * WPL + w == (e & (SB - 1)) && acc ? 0x80000000u : 0u;
                         }
                         if (trace)
                             for (int w = 0; w < WPL; w++)
-                                if (gl * WPL + w <= (step & 15)) hist_at(step & ~15)[w] = (int)stage[gl * WPL + w];
+                                if (gl * WPL + w <= (step & (SB - 1))) hist_at(step & ~(SB - 1))[w] = (int)stage[gl * WPL + w];
                         cold[C_N_ACC] += __popc(accw);
                         if (have_bits && gl == 0) *bits_at(step >> 5) = accw >> (31 - (step & 31));  // (step & 31) + 1 flags so far
                     } else {
@@ -1864,9 +1889,9 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     }
 
     if (active) {  // ran to n_steps: flush the partial last block and word
-        if (trace && (n_steps & 15) != 15)
+        if (trace && (n_steps & (SB - 1)) != SB - 1)
             for (int w = 0; w < WPL; w++)
-                if (gl * WPL + w <= (n_steps & 15)) hist_at(n_steps & ~15)[w] = (int)stage[gl * WPL + w];
+                if (gl * WPL + w <= (n_steps & (SB - 1))) hist_at(n_steps & ~(SB - 1))[w] = (int)stage[gl * WPL + w];
         if ((n_steps & 31) != 0) cold[C_N_ACC] += __popc(accw);
         if (have_bits && gl == 0 && (n_steps & 31) != 0) *bits_at(n_steps >> 5) = accw >> (32 - (n_steps & 31));  // n_steps & 31 flags in the last word
     }
@@ -2044,6 +2069,9 @@ int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_
 int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_of(p) + 3) / 4) + 15) & ~15; }
 #endif
 
+// full_3d: uint16 entries per chain of the packed queen table in the workspace (64-byte rows); 0 for boards
+int qtab_stride_for(const mcq_params* p) { return p->mode == MCQ_MODE_FULL3D ? (queens_of(p) + 31) & ~31 : 0; }
+
 size_t n_sets_of(const mcq_params* p) { return p->n_sets > 1 ? (size_t)p->n_sets : 1; }
 // one table per schedule set, tab_stride elements apart (a 256-byte multiple for either element size)
 size_t tab_stride_for(const mcq_params* p) { return ((size_t)(p->n_steps > 0 ? p->n_steps : 1) + 63) & ~(size_t)63; }
@@ -2057,13 +2085,15 @@ constexpr size_t LADDER_BYTES = 16 * 8;       // replica exchange: the beta mult
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
 // side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
-int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0) {
+int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0, bool slim = false) {
     const int NN = N * N, pad = (N + 3) & ~3;
     if (Q <= 0) Q = NN;  // full_3d: the queens (mcq_params.n_queens); N * N by default
     int w = LDS_STATE;
     if (mode == MCQ_MODE_BOARD) w += (NN + 3) / 4 + (N + 2) / 4;
+    else if (slim) w = 8 + 4 + RING + (2 * pad + NN + 1) / 2;  // SLIM: stage[8] | cold[4] | ring[64] | 16-bit column words; the queens are in global memory
     else w += (narrow ? (2 * pad + NN + 1) / 2 : 2 * pad + NN) + (Q + 1) / 2;
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
+    if (slim) return w;  // (N = 12: 160 words = 640 B, what 16 chains x 16 wavefronts per CU leave; no room for the stride rule below)
     // The chains of a wavefront make many accesses at the SAME offset of their slices (history staging, cold scalars, ring appends):
     // a stride of 4 mod 8 words puts the 8 chains of a 32-lane access group on 8 different banks; 0 mod 8 would serialise them
     // (A/B on the headline problem, same box: profiles/r02_lds_stride_ab.txt, r02_lds_stride_pmc.txt).
@@ -2110,6 +2140,8 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->exch_every = p->exchange_every, a->exch_R = p->exchange_every > 0 ? p->exchange_replicas : 1;
     a->exch_ladder = (const double*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES);
     a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES);
+    a->qtab_stride = qtab_stride_for(p);
+    a->qtab = a->qtab_stride ? (uint16_t*)(a->ws + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * a->rec_words) : nullptr;  // behind the chain records
     a->seeds = seeds, a->out = *out;
 #if defined(MCQ_STAMPS) || defined(MCQ_WAVE_TIMES)
     a->dbg = g_dbg;
@@ -2146,7 +2178,7 @@ int effective_lanes(const mcq_params* p) {
     return G;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -2156,9 +2188,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     if (waves < 2LL * device_simds()) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
     if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -2229,15 +2261,14 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 }
             }
         }
-#ifdef MCQ_EXP_F3D_G4
-        if constexpr (G == 4) {  // experiment: the 16-bit layout with two lanes around each of the two cells, six unrolled passes
+        if constexpr (G == 4) {  // the slim layout: two lanes around each of the two cells, six unrolled passes, the queens in global memory
             if (!a.red && (a.N + 1) / 2 == 6) {
                 KArgs b = a;
-                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q);
-                return launch_sweep<MODE, G, false, 6, false>(b, s);
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q, true);
+                return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 6, false, false, 12, false, false, false, true>(b, s)
+                                               : launch_sweep<MODE, G, false, 6, false, false, 0, false, false, false, true>(b, s);
             }
         }
-#endif
         return a.red ? launch_sweep<MODE, G, false, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);
     } else {
         const bool pat = a.patience >= 0 && a.patience <= a.n_steps;  // a patience beyond n_steps can never stop a chain: the plain variants give the same results
@@ -2406,6 +2437,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
                         }
                 b.seeds = a.seeds + t * (size_t)p->chains_per_set;
                 b.ws = a.ws + t * (size_t)p->chains_per_set * a.rec_words;
+                if (a.qtab) b.qtab = a.qtab + t * (size_t)p->chains_per_set * a.qtab_stride;
                 b.n_chains = p->chains_per_set;
                 HIP_TRY(launch_init(b));
             }
@@ -2462,7 +2494,8 @@ size_t mcq_state_bytes_for(const mcq_params* p) { return validate(p) == MCQ_OK ?
 
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
-    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * rec_words_for(p) * 4;
+    const size_t chains = (size_t)(p->n_chains > 0 ? p->n_chains : 1);
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + chains * rec_words_for(p) * 4 + chains * (size_t)qtab_stride_for(p) * 2;
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
