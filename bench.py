@@ -147,6 +147,40 @@ def timed_region(args, torch, dist, red_dev, step_fn):
     return elapsed
 
 
+def per_rank_table(torch, dist, rank, world, red_dev, values):
+    """What every rank measured, side by side (for reading an N > 1 run without a second lease): `values` is this rank's
+    {name: milliseconds}; one SUM all-reduce of a [world x len(values)] tensor in which a rank fills its own row, AFTER the timed
+    region.  Returns {name: [value of rank 0, 1, ...]} on every rank."""
+    names = sorted(values)
+    t = torch.zeros(world, len(names), dtype=torch.float64, device=red_dev)
+    t[rank] = torch.tensor([float(values[k]) for k in names], dtype=torch.float64, device=red_dev)
+    if dist is not None and world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t.cpu().tolist()
+    return {k: [round(row[i], 4) for row in t] for i, k in enumerate(names)}
+
+
+def roofline_from_pmc(line, pmc, why, kernel_ms, algo_bytes, local_moves):
+    """Fill roofline.traffic / traffic_rate / valu_issue from a PMC entry of this workload and kernel source (or say why not)."""
+    rl = line["roofline"]
+    if not pmc:
+        rl["traffic_note"] = why
+        return
+    rl["traffic"] = pmc["bytes_per_launch"]
+    if algo_bytes:
+        rl["traffic_ratio"] = pmc["bytes_per_launch"] / algo_bytes  # measured fabric bytes over algorithmic bytes (DESIGN.md 4.3)
+    # the same kernel against the same peak on the bytes it really moves (PMC count per launch over the live kernel time)
+    rl["traffic_rate"] = pmc["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+    rl["traffic_frac"] = rl["traffic_rate"] / HBM_PEAK_GBS
+    rl["traffic_source"] = {k: pmc[k] for k in ("kernel_sha256", "commit", "read_bytes", "write_bytes", "l2_hit_rate", "sweep_launches") if k in pmc}
+    if pmc.get("valu_insts_per_launch"):
+        # the on-chip view of the same kernel: wave64 VALU instructions (PMC count of this workload) over the live kernel
+        # time, against one instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32) on 1024 SIMDs at 2.4 GHz
+        ach = pmc["valu_insts_per_launch"] / (kernel_ms * 1e-3) / 1e9
+        rl["valu_issue"] = {"achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                            "frac": ach / VALU_PEAK_GINST, "per_move": pmc["valu_insts_per_launch"] / max(1, local_moves)}
+
+
 def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
     """configs[1] / configs[2]: one DeviceRun per rank."""
     import numpy as np
@@ -173,7 +207,7 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
     seeds = abi.seeds_for(base_seed + rank * args.chains, args.chains)
     run = mcq_amd._lib.DeviceRun(p, seeds, trace=trace, states=not args.no_states)
     stream = torch.cuda.current_stream()
-    init_ms, sweep_ms, last = [], [], {}
+    init_ms, sweep_ms, reduce_ms, last = [], [], [], {}
 
     def step(timed):
         if timed:
@@ -182,8 +216,11 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
             sweep_ms.append(s_ms)
         else:
             run.launch(stream)
+        t_r = time.perf_counter()
         src = run.t if red_dev.type == "cuda" else {k: run.t[k].cpu() for k in ("best_energy", "steps_to_best", "n_accepted", "steps_executed")}
         last["summary"] = dm.reduce_summary(src, dist=dist, device=red_dev)  # ONE packed all-reduce
+        if timed:
+            reduce_ms.append((time.perf_counter() - t_r) * 1e3)  # pack kernels + the collective + the copy of 14 words to the host (it waits for the sweep when that was not timed)
 
     elapsed = timed_region(args, torch, dist, red_dev, step)
     sm = last["summary"]
@@ -221,11 +258,16 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
             "chains_total": total_chains,
             "lanes_per_chain": mcq_amd._lib.effective_lanes(run.p),
             "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; one packed SUM all-reduce for the summary",
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
         },
         "min_energy": sm["min_best"],
         "mean_best_energy": sm["mean_best"],
         "acceptance_rate": sm["acceptance_rate"],
         "kernel_ms": {"init": sum(init_ms) / len(init_ms), "sweep": sweep_avg_ms},
+        "per_rank": per_rank_table(torch, dist, rank, world, red_dev, {"init_ms": sum(init_ms) / len(init_ms), "sweep_ms": sweep_avg_ms,
+                                                                       "reduce_ms": sum(reduce_ms) / len(reduce_ms), "step_ms": elapsed / args.steps * 1e3}),
+        "allreduce": {"per_step": 1, "payload_bytes": 8 * dm.layout_for([(0, 0)], world, per_chain=False, stats=False)[1],
+                      "backend": "none (one process)" if dist is None else dist.get_backend()},
         **({"exchanges_per_chain": float(run.t["n_exchanges"].double().mean().item())} if args.exchange else {}),
         "roofline": {
             "bound": "hbm",
@@ -233,27 +275,13 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc["bytes_per_launch"] if pmc else None,
+            "traffic": None,
             "kernel": "mcq_sweep_kernel",
             "note": "algorithmic bytes = 4.125 B/move (int32 trace entry + accept bit); on the chip the sweep is bound by instruction issue, "
                     "and the MT19937 state stream it carries moves ~25x those bytes (traffic_frac): DESIGN.md 4.3",
         },
     }
-    if pmc:
-        if algo_bytes:
-            line["roofline"]["traffic_ratio"] = pmc["bytes_per_launch"] / algo_bytes  # measured fabric bytes over algorithmic bytes
-        # the same kernel against the same peak on the bytes it really moves (PMC count per launch over the live kernel time)
-        line["roofline"]["traffic_rate"] = pmc["bytes_per_launch"] / (sweep_avg_ms * 1e-3) / 1e9
-        line["roofline"]["traffic_frac"] = line["roofline"]["traffic_rate"] / HBM_PEAK_GBS
-        line["roofline"]["traffic_source"] = {k: pmc[k] for k in ("kernel_sha256", "commit", "read_bytes", "write_bytes", "l2_hit_rate") if k in pmc}
-        if pmc.get("valu_insts_per_launch"):
-            # the on-chip view of the same kernel: wave64 VALU instructions (PMC count of this workload) over the live kernel
-            # time, against one instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32) on 1024 SIMDs at 2.4 GHz
-            ach = pmc["valu_insts_per_launch"] / (sweep_avg_ms * 1e-3) / 1e9
-            line["roofline"]["valu_issue"] = {"achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                                              "frac": ach / VALU_PEAK_GINST, "per_move": pmc["valu_insts_per_launch"] / max(1, local_moves)}
-    else:
-        line["roofline"]["traffic_note"] = why
+    roofline_from_pmc(line, pmc, why, sweep_avg_ms, algo_bytes, local_moves)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker / baseline only; never on the measured path
@@ -326,40 +354,58 @@ def bench_jobs(args, torch, mcq_amd, dist, rank, world, red_dev):
         want, what = "stats", f"beta_start_end_pairs N=24 board sinusoidal 16 pairs x {args.chains}/GPU chains n_steps={n} trace=reduced (per-step sums on device)"
     js = jb.JobSet(jobs, want=want, dist=dist, lanes_per_chain=args.lanes, rng=args.rng)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    kernel_ms, last = [], {}
+    ev.append(torch.cuda.Event(enable_timing=True))
+    kernel_ms, sweeps_ms, reduce_ms, last = [], [], [], {}
 
     def step(timed):
         cur = torch.cuda.current_stream()
         if timed:
             ev[0].record(cur)
         js.launch()                # every launch forks from the current stream ...
+        if timed:                  # ... (an event where they have all joined it again: the sweeps alone) ...
+            for la in js.launches:
+                cur.wait_stream(la.stream)
+            ev[2].record(cur)
+        t_r = time.perf_counter()
         last["res"] = js.reduce()  # ... joins it again, then ONE packed all-reduce
         if timed:
             ev[1].record(cur)
             ev[1].synchronize()
+            reduce_ms.append((time.perf_counter() - t_r) * 1e3)  # host time of reduce(): it waits for the sweeps, so device time of the reduce = all - sweeps
             kernel_ms.append(ev[0].elapsed_time(ev[1]))
+            sweeps_ms.append(ev[0].elapsed_time(ev[2]))
 
     elapsed = timed_region(args, torch, dist, red_dev, step)
     res = last["res"]
     proposed = sum(r["summary"]["proposed"] for r in res)
     accepted = sum(r["summary"]["accepted"] for r in res)
     mins = [r["summary"]["min_best"] for r in res]
+    all_ms, sw_ms = sum(kernel_ms) / len(kernel_ms), sum(sweeps_ms) / len(sweeps_ms)
+    local_moves = sum(int(la.run.t["steps_executed"].sum().item()) for la in js.launches)
+    key = f"{args.config}_c{args.chains}_s{n}" + ("" if args.rng == "mt19937" else f"_{args.rng}")
+    pmc, why = measured_traffic(key)
     line = {
         "metric": METRIC, "value": proposed * args.steps / elapsed, "unit": "moves/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32+f64", "data": "synthetic (seeded initial boards, the reference's seed derivations; MT19937 NumPy-legacy stream)",
         "config": {"workload": what, "chains_total": chains * len(jobs), "launches_per_rank": len(js.launches),
                    "lanes_per_chain": {f"N={int(la.run.p.N)}": mcq_amd._lib.effective_lanes(la.run.p) for la in js.launches},
-                   "parallelism": f"every cell / pair sharded over {world} GPU(s); one packed SUM all-reduce of {js.total_words} int64 words"},
+                   "parallelism": f"every cell / pair sharded over {world} GPU(s); one packed SUM all-reduce of {js.total_words} int64 words",
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "min_energy": min(m for m in mins if m is not None),
         "min_energy_per_job": mins,
         "acceptance_rate": accepted / max(1, proposed),
-        "kernel_ms": {"all_launches": sum(kernel_ms) / len(kernel_ms)},
+        "kernel_ms": {"all_launches": all_ms, "sweeps": sw_ms, "reduce_on_device": all_ms - sw_ms},
+        "per_rank": per_rank_table(torch, dist, rank, world, red_dev, {"sweeps_ms": sw_ms, "launch_and_reduce_ms": all_ms, "reduce_host_ms": sum(reduce_ms) / len(reduce_ms),
+                                                                       "step_ms": elapsed / args.steps * 1e3}),
+        "allreduce": {"per_step": 1, "payload_bytes": 8 * js.total_words, "backend": "none (one process)" if dist is None else dist.get_backend()},
         "roofline": {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None,
                      "kernel": "mcq_sweep_kernel (one per launch)",
-                     "note": "no per-chain trace leaves the kernel in this config (algorithmic HBM bytes ~ 0 per move): the bound is instruction "
-                             "issue / latency, see DESIGN.md"},
+                     "note": "no per-chain trace leaves the kernel in this config (algorithmic HBM bytes ~ 0 per move, so frac = 0 by definition): the "
+                             "bound is instruction issue / latency -- valu_issue (PMC: wave64 VALU instructions of the step's sweep launches over "
+                             "their live time) is the figure to read; traffic = the MT19937 state stream, see DESIGN.md"},
     }
+    roofline_from_pmc(line, pmc, why, sw_ms, 0.0, local_moves)
     if want == "stats":
         r0 = res[0]
         mean, std = jb.mean_std_from_sums(r0["step_sum"], r0["step_sumsq"], r0["step_count"])
@@ -398,11 +444,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # read when the HIP runtime initialises: before torch is imported (see _lib.py)
     import torch
 
     import mcq_amd
 
+    if args.config == "c4":  # 18 launches side by side, one HIP stream each: more hardware queues than the runtime's 4, asked for before
+        mcq_amd._lib.ensure_hw_queues(18)  # the first GPU call of this process (the variable is read when the HIP runtime initialises)
     dist, rank, world, red_dev = init_dist(args, torch)
     fn = bench_single if args.config in ("c2", "c3") else bench_jobs
     line = fn(args, torch, mcq_amd, dist, rank, world, red_dev)

@@ -15,21 +15,27 @@ from . import abi, build as _build
 
 _lib = None
 
-# The drivers run many small launches concurrently (one HIP stream per (init_mode, N) cell or beta pair).  The HIP runtime maps
-# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and launches that share a queue run one after the other: with the
-# default, the 18 launches of measure_min_energy_vs_N at 3 x 1 024 chains each run at a third of the rate they reach with 16
-# queues (profiles/r02_small_launches.txt).  The variable is read when the HIP runtime initialises, so it is set here, at
-# import, unless the user has chosen a value; it does not affect single-stream runs.
-if "GPU_MAX_HW_QUEUES" not in os.environ:
-    os.environ["GPU_MAX_HW_QUEUES"] = "24"
-    # The HIP runtime reads the variable when it initialises.  A process that touched the GPU before importing this package
-    # keeps the runtime's default of 4 queues: say so instead of silently running the drivers' job lists at a third of their
-    # rate.  (Entry points that own the process -- bench.py, `python -m mcq_amd.drivers` -- import this before torch.)
-    _torch = sys.modules.get("torch")
-    if _torch is not None and _torch.cuda.is_initialized():
-        warnings.warn("mcq_amd: the GPU runtime was initialised before this import, so GPU_MAX_HW_QUEUES=24 cannot take effect; "
-                      "job lists of many small launches (drivers.measure_min_energy_vs_N) will share 4 hardware queues. "
-                      "Import mcq_amd first or export GPU_MAX_HW_QUEUES yourself.", RuntimeWarning, stacklevel=2)
+HW_QUEUES = 24
+
+
+def ensure_hw_queues(n_streams):
+    """A job list of many small launches runs one HIP stream per launch.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES
+    hardware queues (default 4) and launches that share a queue run one after the other: with the default, the 18 launches of
+    measure_min_energy_vs_N at 3 x 1 024 chains each run at a third of the rate they reach with 16 queues
+    (profiles/r02_small_launches.txt).  The variable is read when the HIP runtime initialises, so an entry point that is about to
+    launch on more than 4 streams (jobs.JobSet, bench.py --config c4) calls this BEFORE the first GPU call: it sets
+    GPU_MAX_HW_QUEUES=24 unless the user chose a value, and warns when the runtime is already up.  Nothing is changed at import,
+    and nothing at all for runs of up to 4 streams (single launches, bench.py's default, RCCL-only processes).
+    Returns the value in force (None: the runtime's default)."""
+    if n_streams > 4 and "GPU_MAX_HW_QUEUES" not in os.environ:
+        _torch = sys.modules.get("torch")
+        if _torch is not None and _torch.cuda.is_initialized():
+            warnings.warn(f"mcq_amd: {n_streams} concurrent launches, but the GPU runtime was initialised before GPU_MAX_HW_QUEUES could be "
+                          "raised: they will share 4 hardware queues (about a third of the rate).  Export GPU_MAX_HW_QUEUES=24 before the "
+                          "first GPU call.", RuntimeWarning, stacklevel=3)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES)
+    return os.environ.get("GPU_MAX_HW_QUEUES")
 
 
 class McqError(RuntimeError):

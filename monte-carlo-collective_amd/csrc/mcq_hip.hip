@@ -152,6 +152,7 @@ struct KArgs {
     int low_water;            // stream upkeep runs when some chain of the wavefront holds fewer ready words than this
     int init_words;           // init kernel: LDS words per chain
     const double* exch_ladder;  // [exch_R] beta multipliers per rung (workspace)
+    int dry;                  // launch_sweep: check that the chosen variant fits the device and return without launching
     uint16_t* qtab;           // full_3d: the queens of every chain as i | j << 5 | k << 10, [n_chains][qtab_stride] (workspace; the sweep variants that
     int qtab_stride;          // keep their queen table out of LDS work on it, the init kernel fills it)
 };
@@ -1036,7 +1037,9 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // SLIM (full_3d, unrolled 16-bit column words): the layout that lets BASELINE configs[2]'s 65 536 chains of N = 12 run at 4 lanes per chain in ONE
 // resident round (16 chains per wavefront x 16 wavefronts per CU need <= 640 B of LDS per chain): the queen table lives in global memory
 // (KArgs::qtab: one 2-byte read per step once q is known, one write per accepted move), the ring has no mirror (readers wrap their
-// slot indices) and the history is staged 8 entries at a time: stage[8] | cold[4] | ring[64] | column words.
+// slot indices) and the column table no pads (an out-of-board diagonal probe reads -- and discards -- ring words in front of the
+// table and the next chain's staging block behind it; the workgroup's allocation ends in a spare pad for its last chain):
+// stage[16] | cold[4] | ring[64] | column words = 156 words at N = 12, the 624 B of a board chain.
 template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false>
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     uint32_t* pace_row = a.pace + 16u * (((xcc_id & 7u) << 8) | (((hw_id >> 13) & 3u) << 6) | (((hw_id >> 8) & 15u) << 2) | ((hw_id >> 4) & 3u));
     extern __shared__ uint32_t lds[];
     constexpr int CPW = 64 / G;
-    constexpr int SB = SLIM ? 8 : 16;  // history entries staged per chain between two flushes
+    constexpr int SB = 16;             // history entries staged per chain between two flushes
     constexpr int WPL = SB / G;        // ... and how many of them a lane stores in a flush
     // LDS slice of a chain (word offsets): stage[SB] | cold[4] | ring[64 (+ 32 mirrored)] | state
     constexpr int L_STAGE = 0, L_COLD = SB, L_RING = SB + 4, L_STATE = L_RING + RING + (SLIM ? 0 : RING_MIRROR);
@@ -1066,7 +1069,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     const int gl = lane & (G - 1), grp = lane / G;
     const long long chain = (long long)blockIdx.x * CPW + grp;
     const int N = NC ? NC : a.N, NN = N * N, Q = NC ? NC * NC : a.Q;  // (the compile-time-N variants are dispatched for Q = N^2 only)
-    const int full_pad = NC ? (NC + 3) & ~3 : a.full_pad;
+    const int full_pad = SLIM ? 0 : NC ? (NC + 3) & ~3 : a.full_pad;
     const int state_bytes = NC ? (MODE == MCQ_MODE_BOARD ? NC * NC : 3 * NC * NC) : a.state_bytes;
     bool active = chain < a.n_chains;
     constexpr bool reduced = REDUCED;
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
     } else {
         uint32_t* cw32 = base + L_STATE;  // the column table and its pads as 32-bit words
-        const int cwords = (int)((2 * full_pad + NN) * sizeof(colw_t) / 4);
+        const int cwords = (int)(((2 * full_pad + NN) * sizeof(colw_t) + 3) / 4);  // (rounded up: an odd count of 16-bit words ends in half a word)
         for (int w = gl; w < cwords; w += G) cw32[w] = 0;
         for (int c = gl; c < Q; c += G) {
             const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
@@ -1452,6 +1455,9 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 if (upkeep_now) upkeep();  // while those reads are in flight
                 const uint32_t vqi = wq & maskQ;
                 qi = (int)min(vqi, mQ);  // (a used attempt has vqi <= mQ; an unused one must still index inside the queen table)
+                // (SLIM: a 2-byte read from global memory at the head of the step's dependency chain.  Requesting it a whole step ahead --
+                // the position of the next step's first randint(0, Q) word is known once a step's draws are done -- measured nothing at four
+                // wavefronts per SIMD: 232.8 against 232.4 ms, profiles/r04_full3d_slim.txt)
                 oldp = qn[qi];
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN), pc = (int)(w3 & maskN) & 31;
                 const uint32_t cw1 = colw[__mul24(pa, N) + pb];  // word index < 2^10: inside the workgroup's LDS
@@ -1524,6 +1530,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                         stage_no = (int)(seen >> 8);
                     }
                     sequential();
+                    if constexpr (SLIM) asm volatile("" : "+v"(oldp));  // (a queen read from global memory in there is claimed in here: no wait at the merge, where the common path has the stream's block in flight)
                     if constexpr (EARLY_PROBES) load_probes();
                 }
             }
@@ -1744,7 +1751,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             // the common tail of a step: append the entry, flush full blocks, pace
             auto append_entry = [&]() {
                 stage[e & (SB - 1)] = (uint32_t)E | (reduced ? 0x40000000u | (acc << 31) : 0u);  // REDUCED: bit 30 valid entry, bit 31 its step was accepted
-                if ((e & (SB - 1)) == flush_at) {  // one aligned 64-byte segment per chain, 32-byte with SLIM (flush_at = SB - 1, or out of reach without a trace)
+                if ((e & (SB - 1)) == flush_at) {  // one aligned 64-byte segment per chain (flush_at = SB - 1, or out of reach without a trace)
                     // non-temporal: the trace is written once and never read here, so its lines should not push the MT19937 state's
                     // lines out of the L2 (reads 68.0 -> 65.6 B/move, time unchanged; profiles/r02_nt_trace_experiment.txt)
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -2090,10 +2097,9 @@ int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0, bool slim = fal
     if (Q <= 0) Q = NN;  // full_3d: the queens (mcq_params.n_queens); N * N by default
     int w = LDS_STATE;
     if (mode == MCQ_MODE_BOARD) w += (NN + 3) / 4 + (N + 2) / 4;
-    else if (slim) w = 8 + 4 + RING + (2 * pad + NN + 1) / 2;  // SLIM: stage[8] | cold[4] | ring[64] | 16-bit column words; the queens are in global memory
+    else if (slim) w = 16 + 4 + RING + (NN + 1) / 2;  // SLIM: stage[16] | cold[4] | ring[64] | 16-bit column words, no pads; the queens are in global memory
     else w += (narrow ? (2 * pad + NN + 1) / 2 : 2 * pad + NN) + (Q + 1) / 2;
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
-    if (slim) return w;  // (N = 12: 160 words = 640 B, what 16 chains x 16 wavefronts per CU leave; no room for the stride rule below)
     // The chains of a wavefront make many accesses at the SAME offset of their slices (history staging, cold scalars, ring appends):
     // a stride of 4 mod 8 words puts the 8 chains of a 32-lane access group on 8 different banks; 0 mod 8 would serialise them
     // (A/B on the headline problem, same box: profiles/r02_lds_stride_ab.txt, r02_lds_stride_pmc.txt).
@@ -2172,6 +2178,8 @@ int effective_lanes(const mcq_params* p) {
             const int top = p->N <= 8 ? 4 : p->N >= 20 ? 8 : 16;
             while (G < top && (p->n_chains * (2 * G) + 63) / 64 <= room) G *= 2;
         }
+        // full_3d N = 9..12 with a full trace or none, NumPy's stream, no exchange: the slim 4-lane kernels (16 chains per wavefront)
+        if (p->mode == MCQ_MODE_FULL3D && p->N > 8 && p->N <= 12 && p->trace != MCQ_TRACE_REDUCED && p->rng == MCQ_RNG_MT19937_NUMPY && p->exchange_every == 0) G = 4;
         // replica exchange: a ladder lives in one wavefront (its chains swap through cross-lane moves, no barrier)
         if (p->exchange_every > 0 && 64 / G < p->exchange_replicas) G = 64 / p->exchange_replicas;
     }
@@ -2186,8 +2194,11 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     // than two wavefronts on a SIMD would pay for the checkpoints and gain nothing.
     const long long waves = (a.n_chains + CPB - 1) / CPB;
     if (waves < 2LL * device_simds()) a.pace = nullptr;
-    const size_t lds = (size_t)CPB * a.chain_lds_words * 4;
-    if (lds > 160 * 1024) return fail(MCQ_EINVAL, "chain state does not fit in LDS");
+    const size_t lds = (size_t)CPB * a.chain_lds_words * 4 + (SLIM ? 64 : 0);  // (SLIM: the pad behind the last chain's column table)
+    if (lds > 160 * 1024)
+        return fail(MCQ_EINVAL, MODE == MCQ_MODE_FULL3D && a.Q != a.NN ? "chain state does not fit in LDS (n_queens: the queen table of %s chains per wavefront exceeds 160 KB; more lanes_per_chain halve it)"
+                                                                        : "chain state does not fit in LDS (%s chains per wavefront)", G == 2 ? "32" : G == 4 ? "16" : G == 8 ? "8" : "4");
+    if (a.dry) return MCQ_OK;
     HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
     hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM>), dim3(grid), dim3(64), lds, s, a);
@@ -2261,10 +2272,14 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 }
             }
         }
-        if constexpr (G == 4) {  // the slim layout: two lanes around each of the two cells, six unrolled passes, the queens in global memory
-            if (!a.red && (a.N + 1) / 2 == 6) {
+        if constexpr (G == 4) {
+            // the slim layout (N = 9..12): two lanes around each of the two cells, ceil(N / 2) unrolled passes, the queens in global memory.
+            // (65 536 chains x 20 000 steps against 8 lanes: N = 9 53.2 / 65.4 ms, N = 10 49.6 / 62.6, N = 11 60.3 / 62.9, N = 12 52.1 / 59.8;
+            // seven and eight passes spill and lose -- N = 13 129 / 68 ms, N = 16 109 / 91: profiles/r04_full3d_slim.txt)
+            if (!a.red && a.N > 8 && a.N <= 12) {
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q, true);
+                if ((a.N + 1) / 2 == 5) return launch_sweep<MODE, G, false, 5, false, false, 0, false, false, false, true>(b, s);
                 return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 6, false, false, 12, false, false, false, true>(b, s)
                                                : launch_sweep<MODE, G, false, 6, false, false, 0, false, false, false, true>(b, s);
             }
@@ -2369,6 +2384,13 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     rc = build_args(p, seeds, out, workspace, &a);
     if (rc != MCQ_OK) return rc;
 
+    const int G = effective_lanes(p);
+    {  // the variant this launch takes must fit the LDS: found out before anything is enqueued
+        KArgs d = a;
+        d.dry = 1;
+        rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(d, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(d, G, s);
+        if (rc != MCQ_OK) return rc;
+    }
     if (a.out.accept_bits)  // chains that stop early leave their later words untouched
         HIP_TRY(hipMemsetAsync(a.out.accept_bits, 0, (size_t)p->n_chains * p->bits_stride * 8, s));
 
@@ -2446,7 +2468,6 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
 
-    const int G = effective_lanes(p);
     rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
     if (a.red) {

@@ -44,15 +44,17 @@ def _runner_or_default(runner):
 
 def _want(histories, jobs, dist, need_steps):
     """`histories` in (True, False, "auto") -> jobs.JobSet's `want`."""
-    # a full trace row holds at most abi.MAX_TRACE_ENTRIES entries (include/mcq.h: hist_stride < 2^24); the reference takes any
-    # n_steps, so longer runs go through the on-device statistics instead of failing inside the library
+    # a full trace row (abi.hist_stride_for(n_steps) entries: n_steps + 1 rounded up to 64) must stay below abi.MAX_HIST_STRIDE = 2^24
+    # (include/mcq.h: hist_stride < 2^24); the reference takes any n_steps, so longer runs go through the on-device statistics instead
+    # of failing inside the library
     fits = all(abi.hist_stride_for(j["n_steps"]) < abi.MAX_HIST_STRIDE for j in jobs)
     if histories == "auto":
         total = sum(j["n_runs"] * (j["n_steps"] + 1) * 4 for j in jobs)
         histories = dm.rank_world(dist)[1] == 1 and total <= HISTORY_BYTES_AUTO and fits
     if histories:
         if not fits:
-            raise ValueError(f"full histories hold at most {abi.MAX_HIST_STRIDE - 64} steps per chain; use histories=False (on-device statistics) for longer runs")
+            raise ValueError(f"full histories hold at most {abi.MAX_HIST_STRIDE - 65} steps per chain (rows of n_steps + 1 entries, rounded up to 64, below "
+                             f"{abi.MAX_HIST_STRIDE}); use histories=False (on-device statistics) for longer runs")
         return "histories"
     return "stats" if need_steps else "summary"
 
@@ -307,6 +309,8 @@ def main(config="config.yaml", runner=None, dist=None, histories="auto"):
         params = cfg["measure_min_energy_vs_N"]
         sched, base_seed, _desc, sp = ex.build_schedule_from_common(common, n_steps)
         modes = params.get("init_modes", [init_mode])
+        if isinstance(modes, str):  # experiments.py:1302-1305
+            modes = [modes]
         return measure_min_energy_vs_N(params["Ns"], n_steps, sched, schedule_params=sp, init_modes=modes, n_runs=n_runs,
                                        base_seed=base_seed, verbose=verbose, plot=True, out_path=common["output_path"],
                                        mcmc_type=mcmc_type, early_stop_patience=patience, runner=runner, dist=dist)
@@ -326,3 +330,57 @@ def main(config="config.yaml", runner=None, dist=None, histories="auto"):
                                     plot=True, out_path=params.get("output_path"), mcmc_type=mcmc_type,
                                     early_stop_patience=patience, runner=runner, dist=dist, histories=histories)
     raise ValueError(f"Unknown experiment_type: {et}")
+
+
+def _print_like_reference(cfg, res):
+    """What the reference's __main__ prints with `verbose: true` (experiments.py:1264-1266, 1286-1288, 1325-1329, 1359-1362,
+    1386-1390): bare numbers, one per line."""
+    et = cfg["experiment_type"]
+    if et == "single_N":
+        pairs = list(res.values()) if isinstance(res, dict) else [res]
+        for _hist, best in pairs:
+            for e in best:
+                print(e)
+    elif et == "measure_min_energy_vs_N":
+        for mode in res["init_modes"]:
+            for m in res["results"][mode]["mean_min_energies"]:
+                print(m)
+    elif et == "beta_start_end_pairs":
+        for best in res["all_best_energies"].values():
+            print(np.mean(best))
+    elif et == "compare_beta_end":
+        for part in (res["result_N1"], res["result_N2"]):
+            for best in part["all_best_energies"].values():
+                print(np.mean(best))
+
+
+def cli(argv=None):
+    """`python -m mcq_amd [config.yaml]`: the reference's `python experiments.py` (experiments.py:1204-1391) -- reads config.yaml
+    from the working directory unless a path is given, dispatches on experiment_type, prints what the reference prints when
+    `verbose` is set, and writes the CSV data products (no PNGs: plotting is out of scope).  Under torch.distributed.run
+    (WORLD_SIZE > 1) every rank takes its share of each job's chains and rank 0 writes and prints."""
+    import argparse
+
+    ap = argparse.ArgumentParser(prog="python -m mcq_amd", description="MI355X-native drop-in for `python experiments.py` of galgantar/monte-carlo-collective")
+    ap.add_argument("config", nargs="?", default="config.yaml", help="YAML file with the reference's keys (default: ./config.yaml)")
+    ap.add_argument("--histories", choices=("auto", "yes", "no"), default="auto",
+                    help="return full energy histories to the host (yes), use on-device statistics (no), or decide by size (auto)")
+    args = ap.parse_args(argv)
+    cfg = load_config(args.config)
+    dist = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # one process per GPU, RCCL ("nccl") over xGMI
+        import torch
+        import torch.distributed as dist
+
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("MCQ_BACKEND", "nccl"), **({"device_id": torch.device("cuda", local)} if os.environ.get("MCQ_BACKEND", "nccl") == "nccl" else {}))
+    try:
+        res = main(cfg, dist=dist, histories={"auto": "auto", "yes": True, "no": False}[args.histories])
+        if cfg["common"].get("verbose") and _is_writer(dist):
+            _print_like_reference(cfg, res)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
+    return res

@@ -83,7 +83,7 @@ def plan_lanes(shapes, simds, default_lanes):
         that shortens its step -- the job list ends when its slowest launch does.  Closer to the capacity more wavefronts slow
         everybody down: measured on measure_min_energy_vs_N at 1 024 chains per cell, 4 lanes everywhere 199 ms, N = 3 at 16
         lanes 215 ms (profiles/r03_lane_plan.txt).
-    full_3d launches keep the library default.  Returns the list of lane counts."""
+    full_3d launches keep the library default (returned as 0; counted with `default_lanes`).  Returns the list of lane counts."""
     cap = WAVES_PER_SIMD * int(simds)
     waves = lambda n, g: (n + 64 // g - 1) // (64 // g)
     total = lambda pl: sum(waves(n, g) for (_, n, _), g in zip(shapes, pl))
@@ -100,7 +100,9 @@ def plan_lanes(shapes, simds, default_lanes):
         if lds <= 10.6 * 1024 * sum(w for w, b in zip(w4, board) if b):
             plan = four
     if total(plan) > cap:
-        four = [4 if b else g for b, g in zip(board, plan)]
+        # (only where the 4-lane kernels are measured, N <= 24 -- beyond, 16 chains of N x N heights soon exceed the LDS of a CU:
+        # N = 100 at 4 lanes is 169 KB per wavefront and the launch would be refused)
+        four = [4 if b and N <= 24 else g for (N, _, _), b, g in zip(shapes, board, plan)]
         if total(four) <= cap:
             plan = four
     while 2 * total(plan) <= cap:
@@ -112,7 +114,8 @@ def plan_lanes(shapes, simds, default_lanes):
         if 2 * total(trial) > cap:
             break
         plan = trial
-    return plan
+    # full_3d launches are left to the library (0): which kernel family it takes depends on more than N (trace, stream, exchange)
+    return [g if b else 0 for g, b in zip(plan, board)]
 
 
 class _Launch:
@@ -149,13 +152,8 @@ class JobSet:
 
     # ---- GPU path --------------------------------------------------------------------------------------------------
     def _allocate(self, lanes_per_chain, rng):
-        import torch
-
         from . import _lib
 
-        self.torch = torch
-        self.device = torch.device("cuda", torch.cuda.current_device())
-        L = _lib.lib()
         groups = {}
         for i, j in enumerate(self.jobs):
             n = len(self.shards[i][0])
@@ -163,6 +161,12 @@ class JobSet:
             batchable = n > 0 and n % 16 == 0 and j["schedule_params"] is not None
             groups.setdefault(key if batchable else ("single", i), []).append(i)
         groups = {k: ids for k, ids in groups.items() if len(self.shards[ids[0]][0]) > 0}
+        self.hw_queues = _lib.ensure_hw_queues(len(groups))  # one stream per launch: before the first GPU call of the process, if this is it
+        import torch
+
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        L = _lib.lib()
         lanes = {k: lanes_per_chain for k in groups}
         if not lanes_per_chain and len(groups) > 0:  # the launches run side by side: choose their lane counts together
             keys = list(groups)
@@ -194,8 +198,9 @@ class JobSet:
 
         self.launches.sort(key=lambda la: -est(la))
         self.buf = torch.zeros(self.total_words, dtype=torch.int64, device=self.device)
-        # page-locked host copies of the packed tensor, used in turn by reduce(); allocated here, outside anybody's timed region
-        self._host = [torch.empty(self.total_words, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        # page-locked host copies of the packed tensor, used in turn by reduce(): the first one here, outside anybody's timed region; the
+        # second when a second reduce() comes (a one-shot JobSet(...).run() never pays for it)
+        self._host = [None, torch.empty(self.total_words, dtype=torch.int64, pin_memory=True)]
 
     def launch(self):
         """Enqueue every launch on its stream; returns immediately (GPU path) or after the injected runner has run."""
@@ -266,7 +271,11 @@ class JobSet:
     # ---- the reduce ---------------------------------------------------------------------------------------------------
     def reduce(self):
         """Pack this rank's results, all-reduce once, and return one dict per job (identical on every rank):
-        summary, best_energy[n_runs], steps_to_best[n_runs], and with want="stats" the five per-step arrays."""
+        summary, best_energy[n_runs], steps_to_best[n_runs], and with want="stats" the five per-step arrays.
+
+        Lifetime of the returned arrays (GPU path): they are NumPy VIEWS of one of two page-locked host buffers this JobSet owns and
+        uses in turn -- valid through the NEXT reduce() of this JobSet, overwritten by the one after, and pinned memory stays
+        allocated while the JobSet (or any result array) lives.  Copy what must outlive two reduces."""
         if self.runner is None:
             torch = self.torch
             cur = torch.cuda.current_stream()

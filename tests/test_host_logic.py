@@ -38,8 +38,13 @@ def test_lane_plan_of_side_by_side_launches():
     assert jobs.plan_lanes([(17, 512, abi.MODE_BOARD)], simds, _default) == [16]
     assert jobs.plan_lanes([(24, 16384, abi.MODE_BOARD)], simds, _default) == [8]
     assert jobs.plan_lanes([(3, 512, abi.MODE_BOARD)], simds, _default) == [4]
+    # boards beyond the measured 4-lane range are never forced to 4 lanes (N = 100: 16 chains would need 169 KB of LDS)
+    for N in (33, 64, 99, 100, 128):
+        d = _default(abi.MODE_BOARD, N)
+        assert jobs.plan_lanes([(N, 40000, abi.MODE_BOARD)], simds, _default) == [d]
+        assert jobs.plan_lanes([(N, 40000, abi.MODE_BOARD), (12, 40000, abi.MODE_BOARD)], simds, _default)[0] == d
     # full_3d keeps the library's choice
-    assert jobs.plan_lanes([(12, 4096, abi.MODE_FULL3D), (12, 512, abi.MODE_BOARD)], simds, _default)[0] == 8
+    assert jobs.plan_lanes([(12, 4096, abi.MODE_FULL3D), (12, 512, abi.MODE_BOARD)], simds, _default)[0] == 0  # (0 = the library's own choice)
     for N in range(2, 33):
         for g in (4, 8, 16):
             assert jobs.lone_ms(N, g) > 0

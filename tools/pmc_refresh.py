@@ -22,7 +22,10 @@ def main():
     copy_to = sys.argv[3] if len(sys.argv) > 3 else None
     with open(os.path.join(src, "summary.json")) as f:
         summ = json.load(f)
-    d = summ["sweep"]
+    d = dict(summ["sweep"])
+    n_disp = int(d.pop("_dispatches", 1)) or 1
+    if n_disp > 1:  # a job list (bench.py --config c4 / c5 with --steps 1 --warmup 0): the entry holds the SUM over the step's sweep launches
+        d = {k: v * n_disp for k, v in d.items()}
     with open(os.path.join(src, "kernel_sha256.txt")) as f:
         sha_box = f.read().strip()
     with open(os.path.join(ROOT, "monte-carlo-collective_amd", "csrc", "mcq_hip.hip"), "rb") as f:
@@ -37,6 +40,7 @@ def main():
         "kernel_sha256": sha_now,
         "commit": commit + ("+uncommitted kernel edits" if dirty else ""),
         "bench_args": open(os.path.join(src, "bench_args.txt")).read().strip(),
+        "sweep_launches": n_disp,
         "bytes_per_launch": rd + wr,
         "read_bytes": rd,
         "write_bytes": wr,
