@@ -198,7 +198,11 @@ def bench_single(args, torch, mcq_amd, dist, rank, world, red_dev):
                         early_stop_patience=args.patience, trace=trace, lanes_per_chain=args.lanes, rng=args.rng)
     def with_exchange(q):  # replica exchange between the chains of a ladder: NOT a mode of the reference, evidence only
         if args.exchange:
+            if args.replicas not in (2, 4, 8, 16):
+                raise SystemExit("--replicas must be 2, 4, 8 or 16")
             lo, hi = (float(x) for x in args.ladder.split(","))
+            if not (0.0 < lo <= hi < float("inf")):
+                raise SystemExit("--ladder LO,HI: finite positive multipliers, LO <= HI")
             abi.set_exchange(q, args.exchange, lo * (hi / lo) ** (np.arange(args.replicas) / (args.replicas - 1)))
         return q
 

@@ -70,6 +70,14 @@ extern "C" {
 /* flags */
 #define MCQ_FLAG_EXACT_EXP 1u        /* evaluate exp(-beta*dE) in float64 on every step (disable the float32 bracket) */
 #define MCQ_FLAG_SEQUENTIAL_DRAWS 2u /* HIP: draw every proposal word by word (disable the batched selection); for testing */
+#define MCQ_FLAG_LINE_COUNTERS 4u    /* HIP: boards up to N = 8 at 4 lanes per chain take dE from per-line occupancy counters in LDS (one byte per line of
+                                        the 12 families, 2 N^2 + 6 N (2N-1) + 4 (2N-1)^2 bytes per chain) instead of bit-mask probes of the heights; ignored
+                                        where it does not apply (larger N, other lane counts, Philox, reduced trace, exchange).  Never changes a result. */
+/* HIP: bits 8..9 of flags = the hardware priority (s_setprio 0..3) the launch's wavefronts run at when the launch is too small to pace
+ * itself (fewer than two wavefronts per SIMD).  For callers that run several launches side by side: the long ones get precedence, the
+ * short ones fill the gaps.  Never changes a result.  MCQ_FLAG_PRIORITY(p) builds the bits. */
+#define MCQ_FLAG_PRIORITY_SHIFT 8
+#define MCQ_FLAG_PRIORITY(p) (((uint32_t)(p) & 3u) << MCQ_FLAG_PRIORITY_SHIFT)
 
 /* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319; the reference itself is
  * unbounded).  full_3d: column occupancy is one 32-bit word per column.  board: bit masks up to N = 32, a compare per probed
@@ -108,7 +116,7 @@ typedef struct mcq_params {
                                 are written in aligned 64-byte segments; energy_hist itself must be 64-byte aligned; runs of more
                                 than 2^24 - 16 steps take trace = REDUCED or NONE) */
     int64_t bits_stride;     /* uint64 words per chain row of accept_bits, >= ceil(n_steps / 64) */
-    int32_t lanes_per_chain; /* HIP only: 4, 8 or 16 lanes of a wavefront per chain; 0 = library default */
+    int32_t lanes_per_chain; /* HIP only: 2 (boards), 4, 8 or 16 lanes of a wavefront per chain; 0 = library default */
     int32_t device;          /* HIP only, host-buffer entry point: device ordinal, < 0 = current device */
     /* Several schedules in ONE launch (everything else shared): n_sets <= 1 means the single schedule above.  Otherwise
      * chains [t * chains_per_set, (t + 1) * chains_per_set) follow sets[t]; n_chains == n_sets * chains_per_set,
@@ -140,7 +148,10 @@ typedef struct mcq_params {
     int32_t n_queens;              /* full_3d only: Q queens instead of N*N (State3DQueens(N, Q=...), mcmc.py:6-18; metropolis_mcmc(..., Q=...),
                                       experiments.py:199-203), 2 <= Q < N^3, random init only (latin / klarner assume Q = N^2: mcmc.py:21-25);
                                       0 = N*N.  state_bytes becomes 3 Q (mcq_state_bytes_for). */
-    const double* exchange_ladder; /* HOST pointer (also for mcq_run_device), R multipliers */
+    const double* exchange_ladder; /* HOST pointer (also for mcq_run_device), R finite positive multipliers.  Read during the call: validated, and copied to the
+                                      device with a hipMemcpyAsync on the caller's stream from THIS (normally pageable) array, so it must stay valid until
+                                      that copy has run -- mcq_run_host and the Python wrappers keep it alive and synchronise; a caller of mcq_run_device
+                                      keeps it until the stream has passed the call (with exchange the call cannot be part of a stream capture) */
 } mcq_params;
 
 /*

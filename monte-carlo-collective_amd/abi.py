@@ -27,6 +27,13 @@ RNG = {"mt19937": RNG_MT19937_NUMPY, "numpy": RNG_MT19937_NUMPY, "philox": RNG_P
 TRACE_NONE, TRACE_I32, TRACE_REDUCED = 0, 1, 2
 FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
+FLAG_LINE_COUNTERS = 4  # HIP: dE from per-line occupancy counters in LDS (boards up to N = 8 at 4 lanes per chain)
+FLAG_PRIORITY_SHIFT = 8  # bits 8..9: s_setprio level of a small launch's wavefronts (include/mcq.h: MCQ_FLAG_PRIORITY)
+
+
+def flag_priority(p):
+    return (int(p) & 3) << FLAG_PRIORITY_SHIFT
+
 
 MIN_N, MAX_N, MAX_N_BOARD = 2, 32, 128  # include/mcq.h: full_3d up to 32, boards up to 128
 MAX_HIST_STRIDE = 1 << 24  # a full trace row (hist_stride entries) must stay below this: include/mcq.h

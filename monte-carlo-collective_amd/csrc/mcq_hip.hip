@@ -1040,7 +1040,16 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // slot indices) and the column table no pads (an out-of-board diagonal probe reads -- and discards -- ring words in front of the
 // table and the next chain's staging block behind it; the workgroup's allocation ends in a spare pad for its last chain):
 // stage[16] | cold[4] | ring[64] | column words = 156 words at N = 12, the 624 B of a board chain.
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false>
+// CNT (board, 4 lanes per chain, N <= 8; mcq_params.flags & MCQ_FLAG_LINE_COUNTERS): dE from per-line occupancy counters in LDS -- the
+// formulation BASELINE's north star names -- instead of bit-mask probes of the heights.  Two distinct cells attack each other iff they
+// share one of the 13 lines through a cell, and on a board the line along k holds the column's own queen only, so with one byte
+// counter per line of the other 12 families
+//     dE = sum_f cnt[line_f(i, j, new_k)] - sum_f cnt[line_f(i, j, old_k)] + 12
+// (the moving queen sits on every line through its old cell and on none through the new one: every key below contains k).  Every
+// line index is linear in (i, j, k); lane gl of a chain owns the families gl, gl + 4, gl + 8: three counters read for the old cell,
+// three for the new one, and an accepted move writes those six back (+-1) -- 2 N^2 + 6 N (2N - 1) + 4 (2N - 1)^2 bytes per chain
+// (N = 8: 1 748, N = 4: 396), which is what keeps this a variant for small boards (profiles/r04_line_counters.txt).
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false, bool CNT = false>
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
 #endif
@@ -1050,6 +1059,7 @@ template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = fa
 #endif
 __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0 && !SLIM) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
     static_assert(!SLIM || (MODE == MCQ_MODE_FULL3D && NT > 0 && !REDUCED && !PATIENCE), "the slim layout exists for the unrolled full_3d kernels with a full (or no) trace");
+    static_assert(!CNT || (MODE == MCQ_MODE_BOARD && G == 4 && NT == 0 && !EXCH), "line counters: boards at 4 lanes per chain");
     static_assert(G >= 4 || MODE == MCQ_MODE_BOARD, "two lanes per chain: boards only (full_3d splits a chain's lanes between two cells)");
     static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
     WAVE_T0;
@@ -1095,8 +1105,35 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     // ---- load the chain record ----
     uint32_t* rec = a.ws + crow * (long long)a.rec_words;
     const uint8_t* rst = (const uint8_t*)(rec + REC_STATE);
+    // CNT: the counters lie behind the heights and their pad; family f starts at cf_base, and line_f(i, j, k) = cf_base + cf_a i + cf_b j + cf_c k
+    uint8_t* const cnt = (uint8_t*)(base + L_STATE + (NN + 3) / 4 + (N + 2) / 4);
+    int cf_a[3] = {0, 0, 0}, cf_b[3] = {0, 0, 0}, cf_c[3] = {0, 0, 0}, cf_base[3] = {0, 0, 0};
+    if constexpr (CNT) {
+        const int D = 2 * N - 1, o = N - 1;
+        //                   (j,k)  (i,k) (k,i-j) (k,i+j) (j,i-k) (j,i+k) (i,j-k) (i,j+k) (i-j,i-k)  (i-j,i+k) (i+j,i-k) (i+j,i+k)
+        const int fa[12] = {0,     N,    1,      1,      1,      1,      D,      D,      D + 1,     D + 1,    D + 1,    D + 1};
+        const int fb[12] = {N,     0,    -1,     1,      D,      D,      1,      1,      -D,        -D,       D,        D};
+        const int fc[12] = {1,     1,    D,      D,      -1,     1,      -1,     1,      -1,        1,        -1,       1};
+        const int fo[12] = {0,     0,    o,      0,      o,      0,      o,      0,      o * D + o, o * D,    o,        0};
+        const int fs[12] = {NN,    NN,   N * D,  N * D,  N * D,  N * D,  N * D,  N * D,  D * D,     D * D,    D * D,    D * D};
+        int start = 0;
+#pragma unroll
+        for (int f = 0; f < 12; f++) {
+            if ((f & 3) == gl) cf_a[f >> 2] = fa[f], cf_b[f >> 2] = fb[f], cf_c[f >> 2] = fc[f], cf_base[f >> 2] = start + fo[f];
+            start += fs[f];
+        }
+    }
     if (MODE == MCQ_MODE_BOARD) {
         for (int c = gl; c < Q; c += G) hts[c] = rst[c];
+        if constexpr (CNT) {  // count the initial board: every lane walks all columns for its own three families (disjoint bytes: plain read-modify-write)
+            const int total = 2 * NN + 6 * N * (2 * N - 1) + 4 * (2 * N - 1) * (2 * N - 1);
+            for (int w = gl; w < (total + 3) / 4; w += G) ((uint32_t*)cnt)[w] = 0;
+            for (int c = 0; c < Q; c++) {
+                const int ci = c / N, cj = c - ci * N, ck = rst[c];
+#pragma unroll
+                for (int f = 0; f < 3; f++) cnt[cf_base[f] + cf_a[f] * ci + cf_b[f] * cj + cf_c[f] * ck] += 1;
+            }
+        }
     } else {
         uint32_t* cw32 = base + L_STATE;  // the column table and its pads as 32-bit words
         const int cwords = (int)(((2 * full_pad + NN) * sizeof(colw_t) + 3) / 4);  // (rounded up: an odd count of 16-bit words ends in half a word)
@@ -1233,6 +1270,11 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     float m32 = EXCH && active ? (float)a.exch_ladder[rung] : 1.0f;
     int xcount = EXCH ? (int)(a.exch_every > 2147483647LL ? 2147483647LL : a.exch_every) : 0;
     int xpar = 1;  // exchange n = 1, 2, ... offers the rung pairs (t, t + 1) with t = n & 1 (mod 2)
+
+    // A launch that is too small to pace itself (a.pace is null then) runs at the priority its caller names: a job list of launches
+    // side by side gives its long launches precedence, so that they run at the pace of a lone wavefront while the short ones fill
+    // the gaps, instead of everybody sharing alike and the long ones finishing on an empty device (jobs.JobSet; MCQ_FLAG_PRIORITY).
+    if (!a.pace) set_priority((int)((a.flags >> MCQ_FLAG_PRIORITY_SHIFT) & 3u));
 
     STAMP_DECL;
     const int n_steps = (int)a.n_steps;
@@ -1540,7 +1582,20 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             int dE;
             uint32_t newp = 0;
             uint32_t cw_new = 0, cw_old = 0;  // full_3d: occupancy words of the new and of the old cell's column
-            if (MODE == MCQ_MODE_BOARD) {
+            int cix[6] = {0, 0, 0, 0, 0, 0};  // CNT: the lane's three old-cell and three new-cell lines ...
+            int cvl[6] = {0, 0, 0, 0, 0, 0};  // ... and their counts, kept for the write-back of an accepted move
+            if constexpr (CNT) {
+                // conflicts_for_position(i, j, new_k) - conflicts_for_position(i, j, old_k) (mcmc_board.py:147-193) from the line counters
+                int part = 0;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const int t = cf_base[f] + __mul24(cf_a[f], pa) + __mul24(cf_b[f], pb);
+                    cix[f] = t + __mul24(cf_c[f], old_k), cix[3 + f] = t + __mul24(cf_c[f], pc);
+                    cvl[f] = cnt[cix[f]], cvl[3 + f] = cnt[cix[3 + f]];
+                    part += cvl[3 + f] - cvl[f];
+                }
+                dE = group_sum<G>(part) + 12;
+            } else if (MODE == MCQ_MODE_BOARD) {
                 // dE = conflicts(new_k) - conflicts(old_k) (mcmc_board.py:147-193).  Probe the columns on the
                 // four lines of the ij-plane through (i, j).  Column (i2, j2) at distance d holds height h; it
                 // attacks (i, j, k) iff h - k is 0 or +-d.  The cell (i, j) itself is probed once per direction
@@ -1721,6 +1776,12 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             accw = __builtin_amdgcn_alignbit(acc, accw, 1);  // the flag enters at bit 31: after 32 steps the first of them sits in bit 0
             if (MODE == MCQ_MODE_BOARD) {
                 hts[cell] = (uint8_t)(acc ? pc : old_k);  // every lane of the group writes the same byte; a rejected move rewrites the old height
+                if constexpr (CNT) {
+                    if (acc) {  // the queen leaves its twelve old lines and enters the twelve new ones (all 24 distinct: every key contains k)
+#pragma unroll
+                        for (int f = 0; f < 3; f++) cnt[cix[f]] = (uint8_t)(cvl[f] - 1), cnt[cix[3 + f]] = (uint8_t)(cvl[3 + f] + 1);
+                    }
+                }
             } else if (acc) {
                 // mcmc.py:171-183; every lane of the group performs the same writes.  The two column words were read for the own-column
                 // counts of dE: no second LDS round trip here.  A move inside one column changes one word twice: the second
@@ -2057,6 +2118,8 @@ int validate(const mcq_params* p) {
         const int R = p->exchange_replicas;
         if (R != 2 && R != 4 && R != 8 && R != 16) return fail(MCQ_EINVAL, "exchange_replicas must be 2, 4, 8 or 16");
         if (!p->exchange_ladder) return fail(MCQ_EINVAL, "exchange_every > 0 without exchange_ladder");
+        for (int t = 0; t < R; t++)  // a rung runs at beta(step) * ladder[t]: a multiplier that is not a positive finite number has no meaning
+            if (!(p->exchange_ladder[t] > 0.0) || p->exchange_ladder[t] > 1.7976931348623157e308) return fail(MCQ_EINVAL, "exchange_ladder entries must be finite and positive");
         if (p->n_chains % R != 0 || (p->n_sets > 1 && p->chains_per_set % R != 0)) return fail(MCQ_EINVAL, "n_chains (and chains_per_set) must be multiples of exchange_replicas");
         if (p->mode == MCQ_MODE_BOARD && p->patience >= 0 && p->patience <= p->n_steps) return fail(MCQ_EINVAL, "replica exchange needs early stopping off (early_stop_patience None)");
         if (p->trace == MCQ_TRACE_REDUCED) return fail(MCQ_EINVAL, "replica exchange runs with trace none or i32");
@@ -2092,11 +2155,11 @@ constexpr size_t LADDER_BYTES = 16 * 8;       // replica exchange: the beta mult
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
 // side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
-int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0, bool slim = false) {
+int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0, bool slim = false, bool counters = false) {
     const int NN = N * N, pad = (N + 3) & ~3;
     if (Q <= 0) Q = NN;  // full_3d: the queens (mcq_params.n_queens); N * N by default
     int w = LDS_STATE;
-    if (mode == MCQ_MODE_BOARD) w += (NN + 3) / 4 + (N + 2) / 4;
+    if (mode == MCQ_MODE_BOARD) w += (NN + 3) / 4 + (N + 2) / 4 + (counters ? (2 * NN + 6 * N * (2 * N - 1) + 4 * (2 * N - 1) * (2 * N - 1) + 3) / 4 : 0);
     else if (slim) w = 16 + 4 + RING + (NN + 1) / 2;  // SLIM: stage[16] | cold[4] | ring[64] | 16-bit column words, no pads; the queens are in global memory
     else w += (narrow ? (2 * pad + NN + 1) / 2 : 2 * pad + NN) + (Q + 1) / 2;
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
@@ -2186,7 +2249,7 @@ int effective_lanes(const mcq_params* p) {
     return G;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false, bool CNT = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -2199,9 +2262,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
         return fail(MCQ_EINVAL, MODE == MCQ_MODE_FULL3D && a.Q != a.NN ? "chain state does not fit in LDS (n_queens: the queen table of %s chains per wavefront exceeds 160 KB; more lanes_per_chain halve it)"
                                                                         : "chain state does not fit in LDS (%s chains per wavefront)", G == 2 ? "32" : G == 4 ? "16" : G == 8 ? "8" : "4");
     if (a.dry) return MCQ_OK;
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM, CNT>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -2293,6 +2356,15 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 if (!a.red) return launch_sweep<MODE, G, true, 6, false, false, 12>(a, s);
             }
         }
+        if constexpr (G == 4) {
+            // dE from line counters (MCQ_FLAG_LINE_COUNTERS; N <= 8, NumPy's stream, plain or early-stop, full or no trace): see CNT at the kernel
+            if ((a.flags & MCQ_FLAG_LINE_COUNTERS) && a.N <= 8 && !a.red) {
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_BOARD, false, 0, false, true);
+                if (a.N <= 5) return pat ? launch_sweep<MODE, G, true, 0, false, false, 0, false, true, false, false, true>(b, s) : launch_sweep<MODE, G, false, 0, false, false, 0, false, true, false, false, true>(b, s);
+                return pat ? launch_sweep<MODE, G, true, 0, false, false, 0, false, false, false, false, true>(b, s) : launch_sweep<MODE, G, false, 0, false, false, 0, false, false, false, false, true>(b, s);
+            }
+        }
         if constexpr (G == 4) {  // straight-line probe blocks for the common board sizes
             // (early stopping -- the reference's default early_stop_patience = 100000 -- has its own unrolled variants for the
             // sizes that default to 4 lanes)
@@ -2308,6 +2380,15 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
                 return a.N <= 4 ? launch_sweep<MODE, G, false, 1, false, false, 0, false, true>(a, s) : launch_sweep<MODE, G, false, 2, false, false, 0, false, true>(a, s);
             if (!pat && a.N == 12)  // the size of BASELINE config 2: N as a compile-time constant
                 return a.red ? launch_sweep<MODE, G, false, 3, true, false, 12>(a, s) : launch_sweep<MODE, G, false, 3, false, false, 12>(a, s);
+#ifndef MCQ_EXP_NO_NC5  // (timing experiment: without these instantiations)
+            // the long cells of measure_min_energy_vs_N (BASELINE configs[3]): N as a compile-time constant (125 / 119 / 118 VGPRs and 10 / 7 / 4
+            // spilled SGPRs against 128 / 40 of the generic five-pass variant; N = 19 is left out: its instantiation spills 324 VGPRs)
+            if (!pat && !a.red && (a.N == 17 || a.N == 18 || a.N == 20)) switch (a.N) {
+                case 17: return launch_sweep<MODE, G, false, 5, false, false, 17>(a, s);
+                case 18: return launch_sweep<MODE, G, false, 5, false, false, 18>(a, s);
+                default: return launch_sweep<MODE, G, false, 5, false, false, 20>(a, s);
+                }
+#endif
             if (!pat) switch ((a.N + G - 1) / G) {
 #define MCQ_NT_CASE(nt) case nt: return a.red ? launch_sweep<MODE, G, false, (nt >= 4 ? 0 : nt), true>(a, s) : launch_sweep<MODE, G, false, nt, false>(a, s)
                 MCQ_NT_CASE(1);  // N = 2..4
@@ -2334,6 +2415,17 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             if (pat && !a.red && a.N > 16 && a.N <= 24) return roomy ? launch_sweep<MODE, G, true, 3, false, false, 0, false, false, true>(a, s) : launch_sweep<MODE, G, true, 3, false>(a, s);
             if (pat && !a.red && a.N > 24 && a.N <= 32) return launch_sweep<MODE, G, true, 4, false>(a, s);
             if (pat && !a.red && a.N > 8 && a.N <= 16) return launch_sweep<MODE, G, true, 2, false>(a, s);
+        }
+        if constexpr (G == 16) {  // 4 chains per wavefront: one packed probe pass up to N = 16, two unpacked ones up to N = 32
+            // (what a launch far below the device's capacity takes -- 16 384 chains of N = 24, the per-GPU shape of BASELINE configs[4], are
+            // four wavefronts per SIMD this way; before round 4 these widths ran the run-time probe loop)
+            const bool roomy = (a.n_chains + 3) / 4 <= 2LL * device_simds();
+            if (!pat && a.N <= 16) return a.red ? launch_sweep<MODE, G, false, 1, true>(a, s) : launch_sweep<MODE, G, false, 1, false>(a, s);
+            if (!pat && a.red && a.N == 24) return launch_sweep<MODE, G, false, 2, true, false, 24>(a, s);
+            if (!pat && a.N <= 32) {
+                if (a.red) return launch_sweep<MODE, G, false, 2, true>(a, s);
+                return roomy ? launch_sweep<MODE, G, false, 2, false, false, 0, false, false, true>(a, s) : launch_sweep<MODE, G, false, 2, false>(a, s);
+            }
         }
         if (a.red) return pat ? launch_sweep<MODE, G, true, 0, true>(a, s) : launch_sweep<MODE, G, false, 0, true>(a, s);
         return pat ? launch_sweep<MODE, G, true, 0, false>(a, s) : launch_sweep<MODE, G, false, 0, false>(a, s);

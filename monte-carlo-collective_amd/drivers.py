@@ -342,7 +342,7 @@ def _print_like_reference(cfg, res):
             for e in best:
                 print(e)
     elif et == "measure_min_energy_vs_N":
-        for mode in res["init_modes"]:
+        for mode in res["results"]:  # (insertion order = the order of init_modes)
             for m in res["results"][mode]["mean_min_energies"]:
                 print(m)
     elif et == "beta_start_end_pairs":

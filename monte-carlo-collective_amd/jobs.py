@@ -17,6 +17,8 @@ run_beta_start_end_pairs (experiments.py:777-806), one per (init_mode, N) cell i
 
 `want="histories"` is the small-run path that returns full energy histories to the host like the reference does.
 """
+import json
+import os
 import time
 
 import numpy as np
@@ -45,21 +47,34 @@ def _stopped_hist(hist_len, n_steps, xp, **kw):
 
 
 # Step time of ONE board wavefront with the SIMD to itself, ms per 20 000 steps, by N and lanes per chain (4, 8, 16): the measure a
-# job list's lane plan and launch order are built on (tools/lane_table.py on one MI355X, profiles/r03_lane_table.txt).  Lone-wave
-# latency, not throughput: it ranks launches that run side by side below the device's capacity; above it the library default stands.
-_LONE_MS = {
-    2: (11.4, 17.6, 14.6), 3: (11.4, 17.6, 14.6), 4: (9.5, 13.1, 11.8), 5: (11.5, 12.9, 11.9), 6: (11.6, 11.7, 11.0), 7: (10.6, 11.2, 10.6),
-    8: (10.1, 10.8, 10.4), 9: (12.6, 11.4, 10.7), 10: (11.9, 10.9, 10.4), 11: (11.6, 10.7, 10.3), 12: (10.9, 10.5, 10.3), 13: (12.4, 10.4, 10.2),
-    14: (12.3, 10.3, 10.1), 15: (12.1, 10.1, 9.9), 16: (12.1, 10.1, 10.0), 17: (17.7, 14.1, 13.2), 18: (17.4, 13.9, 13.0), 19: (17.3, 13.5, 13.0),
-    20: (17.0, 13.3, 16.3), 21: (24.0, 13.2, 16.3), 22: (23.9, 13.1, 16.2), 23: (23.8, 13.1, 16.1), 24: (23.7, 13.0, 16.1),
-}
+# job list's lane plan and launch order are built on.  Lone-wave latency, not throughput: it ranks launches that run side by side
+# below the device's capacity; above it the library default stands.  The numbers are DATA, not code: lane_table.json next to this
+# file is written by tools/lane_table.py --json on one MI355X together with the sha256 of the kernel source it was measured on, and
+# tests/test_host_logic.py fails when csrc/mcq_hip.hip changes without a new table.
+LANE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lane_table.json")
+
+
+def _load_lane_table(path=LANE_TABLE_PATH):
+    with open(path) as f:
+        d = json.load(f)
+    col = {int(g): k for k, g in enumerate(d["lanes"])}
+    ms = {int(N): tuple(float(x) for x in row) for N, row in d["ms"].items()}
+    if not {4, 8, 16} <= set(col) or not ms:
+        raise ValueError(f"{path}: a lane table needs the columns 4, 8 and 16 lanes and at least one board size")
+    return ms, col, d.get("kernel_sha256")
+
+
+_LONE_MS, _LANE_COL, LANE_TABLE_SHA = _load_lane_table()
 WAVES_PER_SIMD = 4  # resident wavefronts per SIMD of the sweep kernels (their register budget)
 
 
 def lone_ms(N, lanes):
-    """Estimated lone-wavefront sweep time of a board launch per 20 000 steps."""
-    t = _LONE_MS.get(int(N), _LONE_MS[24])
-    return t[{4: 0, 8: 1, 16: 2}[int(lanes)]] * (max(int(N), 24) / 24.0)
+    """Estimated lone-wavefront sweep time of a board launch per 20 000 steps (sizes outside the table: the nearest measured one,
+    scaled with N beyond the largest)."""
+    N = int(N)
+    top = max(_LONE_MS)
+    t = _LONE_MS.get(N) or _LONE_MS[min(_LONE_MS, key=lambda k: abs(k - N))]
+    return t[_LANE_COL[int(lanes)]] * (max(N, top) / float(top))
 
 
 def _lds_bytes_per_wave(N, lanes):
@@ -124,6 +139,7 @@ class _Launch:
     def __init__(self, job_ids, run, n_local, cps):
         self.job_ids, self.run, self.n_local, self.cps = job_ids, run, n_local, cps
         self.stream = None
+        self.priority = 0
         self.no_stops = None  # a zero step_stopped array, shared by the launch's jobs when none of its chains can stop early
 
 
@@ -173,6 +189,12 @@ class JobSet:
             shapes = [(self.jobs[groups[k][0]]["N"], len(self.shards[groups[k][0]][0]) * len(groups[k]),
                        abi.mode_of(self.jobs[groups[k][0]]["mcmc_type"])) for k in keys]
             lanes = dict(zip(keys, plan_lanes(shapes, L.mcq_device_simds(), L.mcq_default_lanes_n)))
+            # (experiments only, tools/r04_shapes.sh: MCQ_LANES_PLAN="17:8,18:8" overrides the plan for boards of those N)
+            for item in filter(None, os.environ.get("MCQ_LANES_PLAN", "").split(",")):
+                n_, g_ = (int(x) for x in item.split(":"))
+                for k, (N, _, m) in zip(keys, shapes):
+                    if N == n_ and m == abi.MODE_BOARD:
+                        lanes[k] = g_
         for key, ids in groups.items():
             j0 = self.jobs[ids[0]]
             n = len(self.shards[ids[0]][0])
@@ -197,6 +219,17 @@ class JobSet:
             return (lone_ms(p.N, g) if p.mode == abi.MODE_BOARD else 2.0 * lone_ms(p.N, 8)) * p.n_steps
 
         self.launches.sort(key=lambda la: -est(la))
+        # Launches that run side by side far below two wavefronts per SIMD each (the (init, N) cells of measure_min_energy_vs_N on one GPU
+        # of a node) do not pace themselves; left alone they share every SIMD alike, the short ones finish early and the long ones end
+        # on a half-empty device.  The longest estimated launches get hardware priority (include/mcq.h: MCQ_FLAG_PRIORITY): they run
+        # close to the pace of a lone wavefront while the others fill the gaps (profiles/r04_priority.txt).  Never changes a result.
+        if len(self.launches) > 1 and os.environ.get("MCQ_JOB_PRIORITY", "1") != "0":
+            ests = [est(la) for la in self.launches]
+            top = ests[0]
+            for la, e in zip(self.launches, ests):
+                prio = 3 if e >= 0.85 * top else 2 if e >= 0.7 * top else 1 if e >= 0.55 * top else 0
+                la.run.p.flags = int(la.run.p.flags) | abi.flag_priority(prio)
+                la.priority = prio
         self.buf = torch.zeros(self.total_words, dtype=torch.int64, device=self.device)
         # page-locked host copies of the packed tensor, used in turn by reduce(): the first one here, outside anybody's timed region; the
         # second when a second reduce() comes (a one-shot JobSet(...).run() never pays for it)

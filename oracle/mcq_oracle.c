@@ -1117,6 +1117,8 @@ static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq
         const int R = p->exchange_replicas;
         if (R != 2 && R != 4 && R != 8 && R != 16) return fail(MCQ_EINVAL, "exchange_replicas must be 2, 4, 8 or 16");
         if (!p->exchange_ladder) return fail(MCQ_EINVAL, "exchange_every > 0 without exchange_ladder");
+        for (int t = 0; t < R; t++)  /* a rung runs at beta(step) * ladder[t]: a multiplier that is not a positive finite number has no meaning */
+            if (!(p->exchange_ladder[t] > 0.0) || p->exchange_ladder[t] > 1.7976931348623157e308) return fail(MCQ_EINVAL, "exchange_ladder entries must be finite and positive");
         if (p->n_chains % R != 0 || (p->n_sets > 1 && p->chains_per_set % R != 0))
             return fail(MCQ_EINVAL, "n_chains (and chains_per_set) must be multiples of exchange_replicas");
         if (p->mode == MCQ_MODE_BOARD && p->patience >= 0 && p->patience <= p->n_steps)

@@ -44,6 +44,13 @@ def test_two_ranks_equal_one_rank():
             assert k in line, k
         assert line["higher_is_better"] is True and line["vs_baseline"] is None and "workload" in line["config"]
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"]) and line["roofline"]["bound"] == "hbm"
+        # what makes an N > 1 run readable afterwards: every rank's own times side by side, the collective's payload, the queue setting
+        n = line.get("n_gpus", two_gpus)
+        assert set(line["per_rank"]) == {"init_ms", "sweep_ms", "reduce_ms", "step_ms"}
+        assert all(len(v) == n and all(x > 0 for x in v) for v in line["per_rank"].values())
+        assert line["allreduce"]["per_step"] == 1 and line["allreduce"]["payload_bytes"] == 8 * (6 + n)
+        assert "gpu_max_hw_queues" in line["config"] and line["config"]["gpu_max_hw_queues"] is None  # c2: one stream, nothing raised
+    assert two["allreduce"]["backend"] == "gloo" and one["allreduce"]["backend"].startswith("none")
 
 
 @pytest.mark.gpu
@@ -84,6 +91,12 @@ def test_bench_starts_its_own_ranks(config):
     assert two["config"]["chains_total"] == one["config"]["chains_total"]
     for k in ("min_energy", "acceptance_rate") + (("mean_best_energy",) if config == "c2" else ("min_energy_per_job",)):
         assert two[k] == one[k], k
+    for line, n in ((one, 1), (two, 2)):
+        assert all(len(v) == n for v in line["per_rank"].values()) and line["allreduce"]["per_step"] == 1
+    if config == "c5":
+        assert set(two["per_rank"]) == {"sweeps_ms", "launch_and_reduce_ms", "reduce_host_ms", "step_ms"}
+        assert two["kernel_ms"]["sweeps"] > 0 and two["kernel_ms"]["reduce_on_device"] >= 0
+        assert two["allreduce"]["payload_bytes"] == 8 * 16 * (6 + 2 + 2 * 1024 + 5 * 3001)
 
 
 def test_self_launch_command(monkeypatch):

@@ -153,6 +153,12 @@ def test_exchange_parameter_errors():
     r = abi.make_params(6, 10, "random", SP, 8, mcmc_type="board", early_stop_patience=None, trace="reduced")
     abi.set_exchange(r, 2, np.ones(4))
     assert L.mcq_workspace_bytes(ctypes.byref(r)) == 0 and b"trace none or i32" in L.mcq_last_error()
+    # a rung runs at beta(step) * ladder[t]: multipliers that are not positive finite numbers are refused by both libraries
+    for bad in (0.0, -1.0, float("nan"), float("inf")):
+        b = abi.set_exchange(abi.make_params(6, 10, "random", SP, 8, mcmc_type="board", early_stop_patience=None), 2, [1.0, bad, 1.2, 1.4])
+        with pytest.raises(ValueError, match="finite and positive"):
+            oracle.run(b, abi.seeds_for(1, 8))
+        assert L.mcq_workspace_bytes(ctypes.byref(b)) == 0 and b"finite and positive" in L.mcq_last_error()
 
 
 # ---- HIP == oracle ---------------------------------------------------------------------------------------------------------

@@ -81,3 +81,18 @@ def test_beta_table_follows_the_parameter_block():
     np.testing.assert_array_equal(abi.host_beta_table(c), tab)
     p._schedules = None  # a hand-filled block: the device evaluates the schedule
     assert abi.host_beta_table(p) is None
+
+
+def test_lane_table_is_data_measured_on_the_current_kernel():
+    """jobs.plan_lanes ranks launches by measured step times (tools/lane_table.py --json on one MI355X): the table carries the sha256
+    of the kernel source it was measured on and must be regenerated when csrc/mcq_hip.hip changes."""
+    import hashlib
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "monte-carlo-collective_amd", "csrc", "mcq_hip.hip"), "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    assert jobs.LANE_TABLE_SHA == sha, "monte-carlo-collective_amd/lane_table.json is stale: run tools/lane_table.py --json on the GPU box (tools/finalize.sh) and copy it in"
+    ms, col, _ = jobs._load_lane_table()
+    assert set(range(3, 25)) <= set(ms) and all(len(r) == 3 and min(r) > 0 for r in ms.values())
+    assert jobs.lone_ms(2, 4) > 0 and jobs.lone_ms(48, 8) == 2 * jobs.lone_ms(24, 8)

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Sweep time of one board launch per (N, lanes per chain): what the occupancy-aware lane choice is tuned on.
-usage (GPU box): python tools/lane_table.py [--chains 3072] [--n-steps 20000] [--Ns 3-24] [--trace none|reduced] [--mode board]"""
+usage (GPU box): python tools/lane_table.py [--chains 3072] [--n-steps 20000] [--Ns 3-24] [--trace none|reduced] [--mode board] [--json OUT]
+
+--json writes the table jobs.plan_lanes reads (monte-carlo-collective_amd/lane_table.json is a copy of it): the milliseconds per
+(N, lanes) together with the sha256 of the kernel source they were measured on; tests/test_host_logic.py fails when
+csrc/mcq_hip.hip changes without a new table."""
 import argparse
+import hashlib
+import json
 import os
 import sys
 
@@ -17,7 +23,9 @@ def main():
     ap.add_argument("--trace", default="none")
     ap.add_argument("--mode", default="board")
     ap.add_argument("--lanes", default="4,8,16")
+    ap.add_argument("--json", default=None)
     args = ap.parse_args()
+    table = {}
     import torch
 
     import mcq_amd
@@ -34,8 +42,18 @@ def main():
             run.launch(st)
             best = min(run.launch_timed(st)[1] for _ in range(2))
             row.append(f"G={G}: {best:8.3f} ms")
+            table.setdefault(str(N), []).append(round(best, 3))
             del run
         print(f"N={N:2d} chains={args.chains} steps={args.n_steps}  " + "   ".join(row), flush=True)
+    if args.json:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with open(os.path.join(root, "monte-carlo-collective_amd", "csrc", "mcq_hip.hip"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+        with open(args.json, "w") as f:
+            json.dump({"kernel_sha256": sha, "what": f"sweep ms of one {args.mode} launch of {args.chains} chains x {args.n_steps} steps, trace {args.trace}, "
+                                                    "per lanes per chain: a wavefront with the SIMD (nearly) to itself",
+                       "chains": args.chains, "n_steps": args.n_steps, "lanes": [int(g) for g in args.lanes.split(",")], "ms": table}, f, indent=1)
+            f.write("\n")
 
 
 if __name__ == "__main__":
