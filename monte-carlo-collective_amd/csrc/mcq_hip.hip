@@ -691,7 +691,12 @@ struct Stream {
             const W4 x0 = *(const W4*)lword(ix0), x1 = *(const W4*)lword(ix1);
             px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
         } else if constexpr (WPL == 4) {
+#ifdef MCQ_EXP_NT_CUR
+            typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+            const u32x4a q = __builtin_nontemporal_load((const u32x4a*)lword(i0));
+#else
             const uint4 q = *(const uint4*)lword(i0);
+#endif
             pa[0] = q.x, pa[1] = q.y, pa[2] = q.z, pa[3] = q.w;
 #ifdef MCQ_EXP_NT_XLOAD
             typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -1500,7 +1505,15 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 // (SLIM: a 2-byte read from global memory at the head of the step's dependency chain.  Requesting it a whole step ahead --
                 // the position of the next step's first randint(0, Q) word is known once a step's draws are done -- measured nothing at four
                 // wavefronts per SIMD: 232.8 against 232.4 ms, profiles/r04_full3d_slim.txt)
+#if defined(MCQ_EXP_QN_SC1)  // timing experiment: the queen read with agent scope (sc1): does the L2 then ask the fabric for less than a 128-byte line?
+                if constexpr (SLIM) oldp = __hip_atomic_load(qn + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else oldp = qn[qi];
+#elif defined(MCQ_EXP_QN_NT)
+                if constexpr (SLIM) oldp = __builtin_nontemporal_load(qn + qi);
+                else oldp = qn[qi];
+#else
                 oldp = qn[qi];
+#endif
                 pa = (int)(w1 & maskN), pb = (int)(w2 & maskN), pc = (int)(w3 & maskN) & 31;
                 const uint32_t cw1 = colw[__mul24(pa, N) + pb];  // word index < 2^10: inside the workgroup's LDS
                 const bool free1 = !((cw1 >> pc) & 1u);
@@ -1791,7 +1804,15 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 const bool same_column = op_i == (uint32_t)pa && op_j == (uint32_t)pb;
                 colw[times_N<NC>((int)op_i, N) + (int)op_j] = (colw_t)cleared;
                 colw[times_N<NC>(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | (1u << pc));
+#if defined(MCQ_EXP_QN_SC1)
+                if constexpr (SLIM) __hip_atomic_store(qn + qi, (uint16_t)newp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else qn[qi] = (uint16_t)newp;
+#elif defined(MCQ_EXP_QN_NT)
+                if constexpr (SLIM) __builtin_nontemporal_store((uint16_t)newp, qn + qi);
+                else qn[qi] = (uint16_t)newp;
+#else
                 qn[qi] = (uint16_t)newp;
+#endif
             }
             E += __mul24((int)acc, dE);  // E += acc ? dE : 0  (|dE| <= 8 N)
             const bool improved = E < best;  // only an accepted move can get below the best so far (E >= best otherwise)
