@@ -176,3 +176,59 @@ def test_random_round3_feature_combinations():
             for f in ("exchange_rung", "n_exchanges"):
                 np.testing.assert_array_equal(got[f], want[f], err_msg=f"{what}: {f}")
         assert got["near_ties"].sum() == 0 and want["near_ties"].sum() == 0, what
+
+
+def _round4_cases(n=int(os.environ.get("MCQ_FUZZ_R4_CASES", "220"))):
+    rng = np.random.default_rng(FUZZ_SEED + 4)
+    scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
+    out = []
+    for c in range(n):
+        kind = str(rng.choice(["two_lanes", "slim", "counters", "lanes16"]))
+        st = str(rng.choice(scheds))
+        sp = {"type": st, "beta_const": float(rng.choice([0.0, 0.3, 1.0, 2.5]))} if st == "constant" else \
+            {"type": st, "beta_start": float(rng.choice([0.1, 0.5, 1.0])), "beta_end": float(rng.choice([2.0, 3.0, 6.0]))}
+        n_steps = int(rng.choice([0, 1, 15, 16, 17, 31, 33, 64, 65, 100, 300, 700])) if not FUZZ_LONG else int(rng.choice([300, 1500, 4000]))
+        k = dict(c=c, kind=kind, sp=sp, n_steps=n_steps, mode="board", Q=None, patience=None, flags=0, lanes=0, rng="mt19937", trace=True,
+                 init=str(rng.choice(["random", "latin", "klarner"])), seed0=int(rng.integers(0, 2**31)))
+        if kind == "two_lanes":  # boards at 32 chains per wavefront: chain counts around 32 and 64, every stream / trace / early-stop form
+            k.update(N=int(rng.choice([2, 3, 5, 8, 9, 11, 12, 12, 13, 16, 17, 24, 32])), lanes=2, n_chains=int(rng.choice([1, 2, 31, 32, 33, 63, 65])),
+                     rng="philox" if rng.random() < 0.25 else "mt19937", trace=[True, False, "reduced"][int(rng.integers(0, 3))])
+            if rng.random() < 0.35:
+                k["patience"] = int(rng.choice([0, 3, 25, 120]))
+        elif kind == "slim":  # full_3d N = 9..12 at the library's lane choice (4: queens in global memory), any queen count, trace or none
+            N = int(rng.choice([9, 10, 11, 12, 12]))
+            k.update(N=N, mode="full_3d", n_chains=int(rng.choice([1, 3, 15, 16, 17, 40])), trace=bool(rng.random() < 0.7), lanes=int(rng.choice([0, 0, 4])))
+            if rng.random() < 0.4:
+                k.update(Q=int(rng.integers(2, min(N ** 3, 1400))), init="random")
+        elif kind == "counters":  # dE from LDS line counters: boards up to N = 8 at 4 lanes
+            k.update(N=int(rng.integers(2, 9)), lanes=4, flags=abi.FLAG_LINE_COUNTERS, n_chains=int(rng.choice([1, 5, 16, 17, 33])), trace=bool(rng.random() < 0.7))
+            if rng.random() < 0.4:
+                k["patience"] = int(rng.choice([0, 3, 25, 120]))
+        else:  # the unrolled 16-lane boards (one packed pass up to N = 16, two unpacked ones up to 32), with a launch priority
+            k.update(N=int(rng.choice([3, 8, 12, 16, 17, 20, 24, 25, 32])), lanes=16, n_chains=int(rng.choice([1, 4, 5, 9])), flags=abi.flag_priority(int(rng.integers(0, 4))),
+                     trace=[True, False, "reduced"][int(rng.integers(0, 3))])
+        out.append(k)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_random_round4_feature_combinations():
+    """The round-4 variants crossed at random: two lanes per chain, the slim full_3d kernels (queen table in global memory), dE from line
+    counters, the unrolled 16-lane boards, launch priorities."""
+    for k in _round4_cases():
+        what = str(k)
+        p = abi.make_params(k["N"], k["n_steps"], k["init"], k["sp"], k["n_chains"], mcmc_type=k["mode"], early_stop_patience=k["patience"],
+                            lanes_per_chain=k["lanes"], rng=k["rng"], Q=k["Q"], trace=k["trace"], flags=k["flags"])
+        seeds = abi.seeds_for(k["seed0"], k["n_chains"])
+        want = oracle.run(p, seeds, n_threads=8, fast=bool(k["c"] & 1))
+        if k["trace"] == "reduced":
+            got, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced")
+            util.assert_results_equal(got, want, what, trace=False)
+            st = mcq_amd.jobs.stats_from_trace(want, k["n_steps"])
+            for f in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+                np.testing.assert_array_equal(got[f], st[f], err_msg=f"{what}: {f}")
+        else:
+            got, _ = mcq_amd._lib.run_host(p, seeds, trace=k["trace"])
+            util.assert_results_equal(got, want, what, trace=bool(k["trace"]))
+        assert got["near_ties"].sum() == 0, what
