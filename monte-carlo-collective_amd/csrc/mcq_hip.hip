@@ -1063,7 +1063,7 @@ template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = fa
 #define MCQ_G2_WAVES 2
 #endif
 __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0 && !SLIM) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
-    static_assert(!SLIM || (MODE == MCQ_MODE_FULL3D && NT > 0 && !REDUCED && !PATIENCE), "the slim layout exists for the unrolled full_3d kernels with a full (or no) trace");
+    static_assert(!SLIM || (MODE == MCQ_MODE_FULL3D && NT > 0 && !PATIENCE), "the slim layout exists for the unrolled full_3d kernels");
     static_assert(!CNT || (MODE == MCQ_MODE_BOARD && G == 4 && NT == 0 && !EXCH), "line counters: boards at 4 lanes per chain");
     static_assert(G >= 4 || MODE == MCQ_MODE_BOARD, "two lanes per chain: boards only (full_3d splits a chain's lanes between two cells)");
     static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
@@ -1183,6 +1183,8 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     const bool force_slow = (a.flags & MCQ_FLAG_SEQUENTIAL_DRAWS) != 0;
     uint32_t batch_mask = force_slow ? 0u : 0xffffffffu;  // wave-uniform
     asm volatile("" : "+s"(batch_mask));
+    uint32_t zero_mark = 0u;  // a zero the compiler cannot see through (load_probes)
+    asm volatile("" : "+s"(zero_mark));
     const bool trace = a.out.energy_hist != nullptr;
     int flush_at = trace ? SB - 1 : 99;
     asm volatile("" : "+s"(flush_at));  // an opaque scalar: one compare per step, whatever the compiler could derive from the 99
@@ -1404,13 +1406,16 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             constexpr bool EARLY_PROBES = MODE == MCQ_MODE_BOARD && NT >= 1 && NT <= (G == 2 ? MCQ_G2_EARLY_NT : 3) && (PACKED || EARLYU);
 #endif
             uint32_t ph[4 * NTP];
-            auto load_probes = [&]() {
+            // (`mark`: 0 where the probes are requested early, an opaque zero in the rare path's second request.  With two plain requests the
+            // compiler merges the byte loads as 8-bit values and widens them again behind the merge: twelve `v_and 0xff` per step in the common
+            // path of the unpacked early variants, 5 % of their vector instructions.  The OR keeps the merge 32 bits wide and costs the rare path only.)
+            auto load_probes = [&](uint32_t mark) {
                 const uint8_t* hrow = hts + __mul24(pa, N);
                 const uint8_t* hj = hts + pb;
 #pragma unroll
                 for (int t = 0; t < NTP; t++) {
                     const int m = pm[t], mN_ = __mul24(m, N);
-                    ph[4 * t] = hrow[m], ph[4 * t + 1] = hj[mN_], ph[4 * t + 2] = hj[mN_ + m - pa], ph[4 * t + 3] = hj[mN_ - m + pa];
+                    ph[4 * t] = hrow[m] | mark, ph[4 * t + 1] = hj[mN_] | mark, ph[4 * t + 2] = hj[mN_ + m - pa] | mark, ph[4 * t + 3] = hj[mN_ - m + pa] | mark;
                 }
             };
 
@@ -1457,7 +1462,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 const int c3 = (int)(w3 & maskN), c4 = (int)(w4 & maskN), c5 = (int)(w5 & maskN);
                 cell = __mul24(pa, N) + pb;  // < 2^10 bytes: whatever the words were, inside the workgroup's LDS
                 old_k = hts[cell];
-                if constexpr (EARLY_PROBES) load_probes();
+                if constexpr (EARLY_PROBES) load_probes(0u);
                 const bool use3 = c3 != old_k, use4 = c4 != old_k;  // new_k is redrawn while it equals old_k (experiments.py:318-319)
                 int kp, p_last;
                 if constexpr (CAND5) {
@@ -1586,7 +1591,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     }
                     sequential();
                     if constexpr (SLIM) asm volatile("" : "+v"(oldp));  // (a queen read from global memory in there is claimed in here: no wait at the merge, where the common path has the stream's block in flight)
-                    if constexpr (EARLY_PROBES) load_probes();
+                    if constexpr (EARLY_PROBES) load_probes(PACKED ? 0u : zero_mark);  // (the packed variants shift by the byte: no widening to pay for)
                 }
             }
 
@@ -1644,7 +1649,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     const uint32_t BB = Bo | (Bn << 16);
                     const uint32_t shd = (uint32_t)(dji + 16), sha = (uint32_t)sij;
                     uint32_t accp = 0;
-                    if constexpr (!EARLY_PROBES) load_probes();
+                    if constexpr (!EARLY_PROBES) load_probes(0u);
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
                         const int m = pm[t];
@@ -1659,7 +1664,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     dE = (int)(both >> 16) - (int)(both & 0xffffu) + 4;
                 } else {
                     if constexpr (UNROLLED) {  // the heights were requested by load_probes (a clamped probe reads cell N - 1 and is discarded)
-                        if constexpr (!EARLY_PROBES) load_probes();
+                        if constexpr (!EARLY_PROBES) load_probes(0u);
 #pragma unroll
                         for (int t = 0; t < NT; t++) probe(pm[t], t + 1 < NT || krc[t] != 0u, ph[4 * t], ph[4 * t + 1], ph[4 * t + 2], ph[4 * t + 3]);
                     } else if constexpr (NT > 0) {
@@ -2262,8 +2267,8 @@ int effective_lanes(const mcq_params* p) {
             const int top = p->N <= 8 ? 4 : p->N >= 20 ? 8 : 16;
             while (G < top && (p->n_chains * (2 * G) + 63) / 64 <= room) G *= 2;
         }
-        // full_3d N = 9..12 with a full trace or none, NumPy's stream, no exchange: the slim 4-lane kernels (16 chains per wavefront)
-        if (p->mode == MCQ_MODE_FULL3D && p->N > 8 && p->N <= 12 && p->trace != MCQ_TRACE_REDUCED && p->rng == MCQ_RNG_MT19937_NUMPY && p->exchange_every == 0) G = 4;
+        // full_3d N = 9..12, NumPy's stream, no exchange: the slim 4-lane kernels (16 chains per wavefront; every trace mode)
+        if (p->mode == MCQ_MODE_FULL3D && p->N > 8 && p->N <= 12 && p->rng == MCQ_RNG_MT19937_NUMPY && p->exchange_every == 0) G = 4;
         // replica exchange: a ladder lives in one wavefront (its chains swap through cross-lane moves, no barrier)
         if (p->exchange_every > 0 && 64 / G < p->exchange_replicas) G = 64 / p->exchange_replicas;
     }
@@ -2360,9 +2365,14 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             // the slim layout (N = 9..12): two lanes around each of the two cells, ceil(N / 2) unrolled passes, the queens in global memory.
             // (65 536 chains x 20 000 steps against 8 lanes: N = 9 53.2 / 65.4 ms, N = 10 49.6 / 62.6, N = 11 60.3 / 62.9, N = 12 52.1 / 59.8;
             // seven and eight passes spill and lose -- N = 13 129 / 68 ms, N = 16 109 / 91: profiles/r04_full3d_slim.txt)
-            if (!a.red && a.N > 8 && a.N <= 12) {
+            if (a.N > 8 && a.N <= 12) {
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q, true);
+                if (a.red) {  // the reduced trace (what the drivers' statistics runs take)
+                    if ((a.N + 1) / 2 == 5) return launch_sweep<MODE, G, false, 5, true, false, 0, false, false, false, true>(b, s);
+                    return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 6, true, false, 12, false, false, false, true>(b, s)
+                                                   : launch_sweep<MODE, G, false, 6, true, false, 0, false, false, false, true>(b, s);
+                }
                 if ((a.N + 1) / 2 == 5) return launch_sweep<MODE, G, false, 5, false, false, 0, false, false, false, true>(b, s);
                 return a.N == 12 && a.Q == 144 ? launch_sweep<MODE, G, false, 6, false, false, 12, false, false, false, true>(b, s)
                                                : launch_sweep<MODE, G, false, 6, false, false, 0, false, false, false, true>(b, s);
