@@ -395,7 +395,8 @@ def bench_jobs(args, torch, mcq_amd, dist, rank, world, red_dev):
         "config": {"workload": what, "chains_total": chains * len(jobs), "launches_per_rank": len(js.launches),
                    "lanes_per_chain": {f"N={int(la.run.p.N)}": mcq_amd._lib.effective_lanes(la.run.p) for la in js.launches},
                    "parallelism": f"every cell / pair sharded over {world} GPU(s); one packed SUM all-reduce of {js.total_words} int64 words",
-                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "cu_partition": getattr(js, "cu_partition", None), "pacing_across_launches": getattr(js, "pacing", None)},  # compute units per launch (in launch order) when the job list gives its launches CUs of their own
         "min_energy": min(m for m in mins if m is not None),
         "min_energy_per_job": mins,
         "acceptance_rate": accepted / max(1, proposed),

@@ -73,6 +73,10 @@ extern "C" {
 #define MCQ_FLAG_LINE_COUNTERS 4u    /* HIP: boards up to N = 8 at 4 lanes per chain take dE from per-line occupancy counters in LDS (one byte per line of
                                         the 12 families, 2 N^2 + 6 N (2N-1) + 4 (2N-1)^2 bytes per chain) instead of bit-mask probes of the heights; ignored
                                         where it does not apply (larger N, other lane counts, Philox, reduced trace, exchange).  Never changes a result. */
+#define MCQ_FLAG_SHARED_PACING 16u   /* HIP: the launch paces its wavefronts (s_setprio by progress) against ALL launches of this process on the device that
+                                        set the flag -- one progress table per device -- and does so whatever its size; without the flag a launch paces itself against
+                                        its own wavefronts only, and only when it puts two or more on a SIMD.  For callers that run several launches of equal length
+                                        side by side (jobs.JobSet).  Never changes a result. */
 /* HIP: bits 8..9 of flags = the hardware priority (s_setprio 0..3) the launch's wavefronts run at when the launch is too small to pace
  * itself (fewer than two wavefronts per SIMD).  For callers that run several launches side by side: the long ones get precedence, the
  * short ones fill the gaps.  Never changes a result.  MCQ_FLAG_PRIORITY(p) builds the bits. */

@@ -65,11 +65,41 @@ def _share_torch_hip_runtime():
         return None
 
 
+_hip = None
+
+
+def hip_runtime():
+    """The HIP runtime library this process uses (PyTorch's bundled copy when torch is installed, else the system's)."""
+    global _hip
+    if _hip is None:
+        _hip = _share_torch_hip_runtime()
+        if _hip is None:
+            _hip = C.CDLL("libamdhip64.so")
+    return _hip
+
+
+def cu_masked_stream(cu_ids, n_cus):
+    """A HIP stream whose kernels run on the compute units `cu_ids` only (hipExtStreamCreateWithCUMask): what a job list uses to give each of
+    its side-by-side launches CUs of its own, so that a CU's instruction cache holds ONE sweep kernel instead of a dozen (jobs.JobSet).
+    Returns the raw hipStream_t (an int), or None when the runtime refuses."""
+    words = (int(n_cus) + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for c in cu_ids:
+        mask[int(c) >> 5] |= 1 << (int(c) & 31)
+    st = C.c_void_p()
+    fn = hip_runtime().hipExtStreamCreateWithCUMask
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    if fn(C.byref(st), words, mask) != 0 or not st.value:
+        return None
+    return st.value
+
+
 def lib():
     """Load csrc/libmcq_hip.so (building it if the sources are newer and hipcc exists)."""
     global _lib
     if _lib is None:
-        _share_torch_hip_runtime()
+        hip_runtime()
         so = _build.SO
         # A diagnostic build of the same library (tools/stamp_profile.sh, tools/wave_times.sh).  Swapping the product library
         # through the environment is opt-in: without MCQ_ALLOW_DIAG=1 the variable is refused, not silently honoured.

@@ -28,6 +28,7 @@ TRACE_NONE, TRACE_I32, TRACE_REDUCED = 0, 1, 2
 FLAG_EXACT_EXP = 1
 FLAG_SEQUENTIAL_DRAWS = 2
 FLAG_LINE_COUNTERS = 4  # HIP: dE from per-line occupancy counters in LDS (boards up to N = 8 at 4 lanes per chain)
+FLAG_SHARED_PACING = 16  # HIP: pace against every launch of the process that sets the flag (one progress table per device)
 FLAG_PRIORITY_SHIFT = 8  # bits 8..9: s_setprio level of a small launch's wavefronts (include/mcq.h: MCQ_FLAG_PRIORITY)
 
 

@@ -2282,7 +2282,7 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
     // Pacing pays when a SIMD holds several wavefronts of this launch (they can only see each other); a launch that puts less
     // than two wavefronts on a SIMD would pay for the checkpoints and gain nothing.
     const long long waves = (a.n_chains + CPB - 1) / CPB;
-    if (waves < 2LL * device_simds()) a.pace = nullptr;
+    if (waves < 2LL * device_simds() && !(a.flags & MCQ_FLAG_SHARED_PACING)) a.pace = nullptr;
     const size_t lds = (size_t)CPB * a.chain_lds_words * 4 + (SLIM ? 64 : 0);  // (SLIM: the pad behind the last chain's column table)
     if (lds > 160 * 1024)
         return fail(MCQ_EINVAL, MODE == MCQ_MODE_FULL3D && a.Q != a.NN ? "chain state does not fit in LDS (n_queens: the queen table of %s chains per wavefront exceeds 160 KB; more lanes_per_chain halve it)"
@@ -2385,6 +2385,18 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             if (a.N == 12) {
                 if (!pat) return a.red ? launch_sweep<MODE, G, false, 6, true, false, 12>(a, s) : launch_sweep<MODE, G, false, 6, false, false, 12>(a, s);
                 if (!a.red) return launch_sweep<MODE, G, true, 6, false, false, 12>(a, s);
+            }
+            // the other sizes up to N = 12 without early stop and with a full trace or none: what a job list takes for its SHORT launches when it
+            // balances the lanes of launches that run side by side (half the wavefronts of 4 lanes, a longer step: jobs.plan_lanes)
+            if (!pat && !a.red && a.N <= 12) {
+                if (a.N <= 4) return launch_sweep<MODE, G, false, 2, false, false, 0, false, true>(a, s);  // (five candidates for new_k, like the 4-lane kernels of N <= 5)
+                if (a.N == 5) return launch_sweep<MODE, G, false, 3, false, false, 0, false, true>(a, s);
+                switch ((a.N + 1) / 2) {
+                case 3: return launch_sweep<MODE, G, false, 3, false>(a, s);
+                case 4: return launch_sweep<MODE, G, false, 4, false>(a, s);
+                case 5: return launch_sweep<MODE, G, false, 5, false>(a, s);
+                default: return launch_sweep<MODE, G, false, 6, false>(a, s);
+                }
             }
         }
         if constexpr (G == 4) {
@@ -2518,7 +2530,22 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         HIP_TRY(hipMemsetAsync(a.out.accept_bits, 0, (size_t)p->n_chains * p->bits_stride * 8, s));
 
     if (a.red) HIP_TRY(hipMemsetAsync(a.red, 0, red_bytes(p), s));
-    HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
+    if (p->flags & MCQ_FLAG_SHARED_PACING) {
+        // The launches of a job list that run side by side pace their wavefronts against EACH OTHER: one progress table per device for all
+        // launches that set the flag (a wavefront's row and slot come from the hardware's SIMD / wave-slot ids, which are unique whatever
+        // kernel a wavefront belongs to), never cleared in between -- a wavefront that ends writes a zero, a new one publishes after 64 steps.
+        static uint32_t* shared_pace[64] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) return fail(MCQ_EDEVICE, "device ordinal out of range");
+        if (!shared_pace[dev]) {
+            HIP_TRY(hipMalloc((void**)&shared_pace[dev], PACE_BYTES));
+            HIP_TRY(hipMemset(shared_pace[dev], 0, PACE_BYTES));
+        }
+        a.pace = shared_pace[dev];
+    } else {
+        HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
+    }
     if (p->exchange_every > 0)  // 16 doubles at most, from the caller's (host) array
         HIP_TRY(hipMemcpyAsync((void*)a.exch_ladder, p->exchange_ladder, (size_t)p->exchange_replicas * 8, hipMemcpyHostToDevice, s));
     // init kernel: LDS per chain = the MT19937 words, the state, and behind it the permutation array of np.random.choice (full_3d random

@@ -74,7 +74,10 @@ def lone_ms(N, lanes):
     N = int(N)
     top = max(_LONE_MS)
     t = _LONE_MS.get(N) or _LONE_MS[min(_LONE_MS, key=lambda k: abs(k - N))]
-    return t[_LANE_COL[int(lanes)]] * (max(N, top) / float(top))
+    lanes = int(lanes)
+    if lanes not in _LANE_COL:  # (2 lanes per chain: 32 chains per wavefront, measured 1.3-1.45 x the step of 4 lanes for N = 3..12, profiles/r04_shapes.txt)
+        return 1.4 * t[_LANE_COL[4]] * (max(N, top) / float(top))
+    return t[_LANE_COL[lanes]] * (max(N, top) / float(top))
 
 
 def _lds_bytes_per_wave(N, lanes):
@@ -210,8 +213,7 @@ class JobSet:
                 seeds = self.shards[ids[0]][0]
             run = _lib.DeviceRun(p, seeds, trace=self.trace, states=False)
             la = _Launch(ids, run, n, n)
-            la.stream = torch.cuda.Stream()
-            self.launches.append(la)
+            self.launches.append(la)  # (its stream: below, once it is known whether the launches get CUs of their own)
         # longest first, by the estimated time of one of its wavefronts: the launches that follow fill in behind it
         def est(la):
             p = la.run.p
@@ -223,17 +225,92 @@ class JobSet:
         # of a node) do not pace themselves; left alone they share every SIMD alike, the short ones finish early and the long ones end
         # on a half-empty device.  The longest estimated launches get hardware priority (include/mcq.h: MCQ_FLAG_PRIORITY): they run
         # close to the pace of a lone wavefront while the others fill the gaps (profiles/r04_priority.txt).  Never changes a result.
-        if len(self.launches) > 1 and os.environ.get("MCQ_JOB_PRIORITY", "1") != "0":
+        # Better still (and the default): the launches pace EACH OTHER.  A sweep kernel paces its wavefronts through a progress table -- every 64 steps
+        # a wavefront takes the priority "number of co-resident wavefronts ahead of me" (+13 % on a full device) -- but only against
+        # wavefronts of its own launch and only when it puts two or more on a SIMD; the launches of a job list put a fraction of a wavefront on a SIMD
+        # each, so nobody paced anybody and the SIMD arbiter served the oldest wavefront first.  MCQ_FLAG_SHARED_PACING gives all launches of the
+        # list ONE table (rows and slots are the hardware's SIMD / wave-slot ids, unique across kernels; progress = the step, equal-length launches):
+        # measure_min_energy_vs_N at 1 024 chains per cell 200 -> 181 ms, at 512 175 -> 152 ms (profiles/r04_shapes.txt).  MCQ_JOB_PACING=0 falls back
+        # to the static priorities.
+        self.pacing = "none"
+        total_waves = sum((int(la.run.p.n_chains) * _lib.effective_lanes(la.run.p) + 63) // 64 for la in self.launches)
+        one_round = total_waves <= WAVES_PER_SIMD * int(L.mcq_device_simds())  # (beyond one resident round it measures nothing, or -2 % at 8 192 chains per cell)
+        if len(self.launches) > 1 and one_round and os.environ.get("MCQ_JOB_PACING", "1") != "0":
+            for la in self.launches:
+                la.run.p.flags = int(la.run.p.flags) | abi.FLAG_SHARED_PACING
+            self.pacing = "shared"
+        elif len(self.launches) > 1 and os.environ.get("MCQ_JOB_PRIORITY", "1") != "0":
+            self.pacing = "static priorities"
             ests = [est(la) for la in self.launches]
             top = ests[0]
             for la, e in zip(self.launches, ests):
                 prio = 3 if e >= 0.85 * top else 2 if e >= 0.7 * top else 1 if e >= 0.55 * top else 0
                 la.run.p.flags = int(la.run.p.flags) | abi.flag_priority(prio)
                 la.priority = prio
+        self._partition_cus(L)
+        for la in self.launches:  # (a stream is a hardware queue: the plain ones are created only where no masked one was -- 18 + 18 queues oversubscribe the device's
+            if la.stream is None:  # queue slots, and the scheduler then runs the launches one after the other: 3.4 s instead of 0.2 s, profiles/r04_cu_partition.txt)
+                la.stream = torch.cuda.Stream()
         self.buf = torch.zeros(self.total_words, dtype=torch.int64, device=self.device)
         # page-locked host copies of the packed tensor, used in turn by reduce(): the first one here, outside anybody's timed region; the
         # second when a second reduce() comes (a one-shot JobSet(...).run() never pays for it)
         self._host = [None, torch.empty(self.total_words, dtype=torch.int64, pin_memory=True)]
+
+    def _partition_cus(self, L):
+        """Compute units of their own for the launches of a list that run side by side far below the device's capacity (the (init, N) cells of
+        measure_min_energy_vs_N on one GPU of a node: 18 different sweep kernels, 192 wavefronts each).  Left to the dispatcher, every CU ends up
+        with wavefronts of a dozen different kernels, whose hot loops (12-20 KB each) take turns in its instruction cache: the kernel trace shows
+        all 18 running the whole 190 ms, the 2-pass boards three times as long as alone.  With a CU mask per stream a CU runs ONE kernel; the CUs are
+        shared out so that the launches end together: launch i gets c_i CUs with lone_i (w_i / (4 c_i) + 2.9) equal for all i (the occupancy curve
+        T(k) = a k / (k + 2.9) of DESIGN.md 4.3), at most 4 wavefronts per SIMD, the spare CUs to the longest launches.  profiles/r04_cu_partition.txt"""
+        self.cu_partition = None
+        if len(self.launches) < 2 or os.environ.get("MCQ_CU_PARTITION", "0") != "1":
+            return
+        from . import _lib
+
+        torch = self.torch
+        n_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        info = []
+        for la in self.launches:
+            p = la.run.p
+            g = _lib.effective_lanes(p)
+            waves = (int(p.n_chains) * g + 63) // 64
+            lone = (lone_ms(p.N, g) if p.mode == abi.MODE_BOARD else 2.0 * lone_ms(p.N, 8)) * max(1, int(p.n_steps))
+            info.append((waves, lone))
+        # only for lists of SMALL launches: every one below two wavefronts per SIMD of the whole device, all of them together within its capacity
+        if any(w >= 2 * 4 * n_cus for w, _ in info) or sum(w for w, _ in info) > WAVES_PER_SIMD * 4 * n_cus:
+            return
+        floor = [max(1, -(-w // (4 * WAVES_PER_SIMD))) for w, _ in info]  # CUs that hold all wavefronts of the launch at once
+        if sum(floor) > n_cus:
+            return
+
+        def cus_for(t):  # CUs per launch so that each takes time t by the occupancy curve
+            out = []
+            for (w, lone), f in zip(info, floor):
+                k = 3.9 * t / lone - 2.9  # wavefronts per SIMD at which the launch takes t
+                out.append(max(f, int(-(-w // (4 * k))) if k > 0 else n_cus))
+            return out
+
+        lo, hi = 0.0, 50.0 * max(lone for _, lone in info)
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (lo, mid) if sum(cus_for(mid)) <= n_cus else (mid, hi)
+        cus = cus_for(hi)
+        order = sorted(range(len(cus)), key=lambda i: -info[i][1])
+        spare, k = n_cus - sum(cus), 0
+        while spare > 0:  # what the rounding left goes to the longest launches
+            cus[order[k % len(order)]] += 1
+            spare, k = spare - 1, k + 1
+        streams, first = [], 0
+        for c in cus:
+            h = _lib.cu_masked_stream(range(first, first + c), n_cus)
+            if h is None:  # the runtime refuses: keep the plain streams
+                return
+            streams.append(h)
+            first += c
+        for la, h in zip(self.launches, streams):
+            la.stream = torch.cuda.ExternalStream(h, device=self.device)
+        self.cu_partition = cus
 
     def launch(self):
         """Enqueue every launch on its stream; returns immediately (GPU path) or after the injected runner has run."""
@@ -242,8 +319,14 @@ class JobSet:
             self._run_injected()
         else:
             cur = self.torch.cuda.current_stream()
+            # ONE event on the current stream for all launches to wait on.  (An event per launch is an operation on the current stream between two
+            # launches; CU-masked streams are "blocking" streams in HIP's sense -- hipExtStreamCreateWithCUMask takes no flags -- and torch's default
+            # current stream is the legacy default stream, with which a blocking stream synchronises on every operation: the launches then ran one
+            # after the other, 3.4 s instead of 0.2 s.)
+            ready = self.torch.cuda.Event()
+            ready.record(cur)
             for la in self.launches:
-                la.stream.wait_stream(cur)
+                la.stream.wait_event(ready)
                 la.run.launch(stream=la.stream)
         self.launch_seconds = time.perf_counter() - t0
 

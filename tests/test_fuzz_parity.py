@@ -205,7 +205,7 @@ def _round4_cases(n=int(os.environ.get("MCQ_FUZZ_R4_CASES", "220"))):
             if rng.random() < 0.4:
                 k["patience"] = int(rng.choice([0, 3, 25, 120]))
         else:  # the unrolled 16-lane boards (one packed pass up to N = 16, two unpacked ones up to 32), with a launch priority
-            k.update(N=int(rng.choice([3, 8, 12, 16, 17, 20, 24, 25, 32])), lanes=16, n_chains=int(rng.choice([1, 4, 5, 9])), flags=abi.flag_priority(int(rng.integers(0, 4))),
+            k.update(N=int(rng.choice([3, 8, 12, 16, 17, 20, 24, 25, 32])), lanes=16, n_chains=int(rng.choice([1, 4, 5, 9])), flags=abi.flag_priority(int(rng.integers(0, 4))) | (abi.FLAG_SHARED_PACING if rng.random() < 0.5 else 0),
                      trace=[True, False, "reduced"][int(rng.integers(0, 3))])
         out.append(k)
     return out
