@@ -257,60 +257,53 @@ class JobSet:
         self._host = [None, torch.empty(self.total_words, dtype=torch.int64, pin_memory=True)]
 
     def _partition_cus(self, L):
-        """Compute units of their own for the launches of a list that run side by side far below the device's capacity (the (init, N) cells of
-        measure_min_energy_vs_N on one GPU of a node: 18 different sweep kernels, 192 wavefronts each).  Left to the dispatcher, every CU ends up
-        with wavefronts of a dozen different kernels, whose hot loops (12-20 KB each) take turns in its instruction cache: the kernel trace shows
-        all 18 running the whole 190 ms, the 2-pass boards three times as long as alone.  With a CU mask per stream a CU runs ONE kernel; the CUs are
-        shared out so that the launches end together: launch i gets c_i CUs with lone_i (w_i / (4 c_i) + 2.9) equal for all i (the occupancy curve
-        T(k) = a k / (k + 2.9) of DESIGN.md 4.3), at most 4 wavefronts per SIMD, the spare CUs to the longest launches.  profiles/r04_cu_partition.txt"""
+        """Compute units of their own for GROUPS of the launches of a list that fills the device to less than 60 % (MCQ_CU_PARTITION=0 never, =1 whenever the list
+        fits one resident round).  What a CU mask means on this device
+        (tools/cu_mask_probe2.py, profiles/r04_cu_partition.txt): bit i belongs to XCD i % 8, an XCD's bits go round its 4 shader engines, workgroups are
+        split evenly over XCDs and engines (so a launch runs at the pace of its worst-served engine), and an XCD without any bit is unrestricted.  The
+        only clean units are therefore the 8 "layers" of 32 CUs (one CU in every engine of every XCD) = the 8 words of the mask: the launches are put
+        into up to 8 groups of equal estimated work (longest first, each into the lightest group) and a group gets one layer."""
         self.cu_partition = None
-        if len(self.launches) < 2 or os.environ.get("MCQ_CU_PARTITION", "0") != "1":
+        mode = os.environ.get("MCQ_CU_PARTITION", "auto")
+        if len(self.launches) < 2 or mode == "0":
             return
         from . import _lib
 
         torch = self.torch
         n_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
-        info = []
+        layers = n_cus // 32
+        if layers < 2:
+            return
+        work = []
         for la in self.launches:
             p = la.run.p
             g = _lib.effective_lanes(p)
             waves = (int(p.n_chains) * g + 63) // 64
             lone = (lone_ms(p.N, g) if p.mode == abi.MODE_BOARD else 2.0 * lone_ms(p.N, 8)) * max(1, int(p.n_steps))
-            info.append((waves, lone))
-        # only for lists of SMALL launches: every one below two wavefronts per SIMD of the whole device, all of them together within its capacity
-        if any(w >= 2 * 4 * n_cus for w, _ in info) or sum(w for w, _ in info) > WAVES_PER_SIMD * 4 * n_cus:
+            work.append(waves * lone)
+        total = sum((int(la.run.p.n_chains) * _lib.effective_lanes(la.run.p) + 63) // 64 for la in self.launches)
+        # Where it pays (tools/r04_cu_partition.sh): the dispatcher does not spread small launches over the device -- two launches of 192 wavefronts side by side
+        # take 14.6 ms where one takes 10.7 -- so a list that fills the device to 42 % runs 145 -> 101 ms on layers; at 84 % it measures nothing (180 / 186 ms).
+        if total > WAVES_PER_SIMD * 4 * n_cus or (mode != "1" and (len(self.launches) < 4 or total > 0.6 * WAVES_PER_SIMD * 4 * n_cus)):
             return
-        floor = [max(1, -(-w // (4 * WAVES_PER_SIMD))) for w, _ in info]  # CUs that hold all wavefronts of the launch at once
-        if sum(floor) > n_cus:
-            return
-
-        def cus_for(t):  # CUs per launch so that each takes time t by the occupancy curve
-            out = []
-            for (w, lone), f in zip(info, floor):
-                k = 3.9 * t / lone - 2.9  # wavefronts per SIMD at which the launch takes t
-                out.append(max(f, int(-(-w // (4 * k))) if k > 0 else n_cus))
-            return out
-
-        lo, hi = 0.0, 50.0 * max(lone for _, lone in info)
-        for _ in range(60):
-            mid = 0.5 * (lo + hi)
-            lo, hi = (lo, mid) if sum(cus_for(mid)) <= n_cus else (mid, hi)
-        cus = cus_for(hi)
-        order = sorted(range(len(cus)), key=lambda i: -info[i][1])
-        spare, k = n_cus - sum(cus), 0
-        while spare > 0:  # what the rounding left goes to the longest launches
-            cus[order[k % len(order)]] += 1
-            spare, k = spare - 1, k + 1
-        streams, first = [], 0
-        for c in cus:
-            h = _lib.cu_masked_stream(range(first, first + c), n_cus)
-            if h is None:  # the runtime refuses: keep the plain streams
+        n_groups = min(layers, len(self.launches))
+        load, member = [0.0] * n_groups, [0] * len(self.launches)
+        for i in sorted(range(len(work)), key=lambda k: -work[k]):
+            gmin = min(range(n_groups), key=lambda k: load[k])
+            member[i], load[gmin] = gmin, load[gmin] + work[i]
+        # spare layers (fewer groups than layers) go to the heaviest groups
+        own = [[k] for k in range(n_groups)]
+        for extra in range(n_groups, layers):
+            own[max(range(n_groups), key=lambda k: load[k] / len(own[k]))].append(extra)
+        for la, gidx in zip(self.launches, member):
+            ids = [32 * layer + b for layer in own[gidx] for b in range(32)]
+            h = _lib.cu_masked_stream(ids, n_cus)
+            if h is None:  # the runtime refuses: plain streams
+                for lb in self.launches:
+                    lb.stream = None
                 return
-            streams.append(h)
-            first += c
-        for la, h in zip(self.launches, streams):
             la.stream = torch.cuda.ExternalStream(h, device=self.device)
-        self.cu_partition = cus
+        self.cu_partition = member
 
     def launch(self):
         """Enqueue every launch on its stream; returns immediately (GPU path) or after the injected runner has run."""
