@@ -95,6 +95,14 @@ def cu_masked_stream(cu_ids, n_cus):
     return st.value
 
 
+def destroy_stream(handle):
+    """hipStreamDestroy for a stream made by cu_masked_stream (after the work on it has been waited for)."""
+    fn = hip_runtime().hipStreamDestroy
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p]
+    fn(C.c_void_p(handle))
+
+
 def lib():
     """Load csrc/libmcq_hip.so (building it if the sources are newer and hipcc exists)."""
     global _lib

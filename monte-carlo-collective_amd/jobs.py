@@ -295,15 +295,32 @@ class JobSet:
         own = [[k] for k in range(n_groups)]
         for extra in range(n_groups, layers):
             own[max(range(n_groups), key=lambda k: load[k] / len(own[k]))].append(extra)
+        self._masked = []
         for la, gidx in zip(self.launches, member):
             ids = [32 * layer + b for layer in own[gidx] for b in range(32)]
             h = _lib.cu_masked_stream(ids, n_cus)
             if h is None:  # the runtime refuses: plain streams
                 for lb in self.launches:
                     lb.stream = None
+                self.close()
                 return
+            self._masked.append(h)
             la.stream = torch.cuda.ExternalStream(h, device=self.device)
         self.cu_partition = member
+
+    def close(self):
+        """Release the CU-masked HIP streams of this JobSet (torch does not own external streams).  Called on garbage collection too."""
+        from . import _lib
+
+        for h in getattr(self, "_masked", []):
+            try:
+                _lib.destroy_stream(h)
+            except Exception:  # interpreter shutdown: the runtime may be gone already
+                pass
+        self._masked = []
+
+    def __del__(self):
+        self.close()
 
     def launch(self):
         """Enqueue every launch on its stream; returns immediately (GPU path) or after the injected runner has run."""
