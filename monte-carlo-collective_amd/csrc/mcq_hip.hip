@@ -59,6 +59,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/mcq.h"
@@ -1062,7 +1063,7 @@ template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = fa
 #ifndef MCQ_G2_WAVES
 #define MCQ_G2_WAVES 2
 #endif
-__global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0 && !SLIM) ? 2 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
+__global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0 && !SLIM) ? 2 : (SLIM && NT > 6) ? 3 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
     static_assert(!SLIM || (MODE == MCQ_MODE_FULL3D && NT > 0 && !PATIENCE), "the slim layout exists for the unrolled full_3d kernels");
     static_assert(!CNT || (MODE == MCQ_MODE_BOARD && G == 4 && NT == 0 && !EXCH), "line counters: boards at 4 lanes per chain");
     static_assert(G >= 4 || MODE == MCQ_MODE_BOARD, "two lanes per chain: boards only (full_3d splits a chain's lanes between two cells)");
@@ -2365,6 +2366,13 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
             // the slim layout (N = 9..12): two lanes around each of the two cells, ceil(N / 2) unrolled passes, the queens in global memory.
             // (65 536 chains x 20 000 steps against 8 lanes: N = 9 53.2 / 65.4 ms, N = 10 49.6 / 62.6, N = 11 60.3 / 62.9, N = 12 52.1 / 59.8;
             // seven and eight passes spill and lose -- N = 13 129 / 68 ms, N = 16 109 / 91: profiles/r04_full3d_slim.txt)
+#ifdef MCQ_EXP_SLIM16  // experiment: seven and eight passes (N = 13..16) at the register budget of three wavefronts per SIMD, which is all their LDS allows anyway
+            if (!a.red && a.N > 12 && a.N <= 16) {
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q, true);
+                return (a.N + 1) / 2 == 7 ? launch_sweep<MODE, G, false, 7, false, false, 0, false, false, false, true>(b, s) : launch_sweep<MODE, G, false, 8, false, false, 0, false, false, false, true>(b, s);
+            }
+#endif
             if (a.N > 8 && a.N <= 12) {
                 KArgs b = a;
                 b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, true, a.Q, true);
@@ -2534,15 +2542,25 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
         // The launches of a job list that run side by side pace their wavefronts against EACH OTHER: one progress table per device for all
         // launches that set the flag (a wavefront's row and slot come from the hardware's SIMD / wave-slot ids, which are unique whatever
         // kernel a wavefront belongs to), never cleared in between -- a wavefront that ends writes a zero, a new one publishes after 64 steps.
+        // (allocated and cleared once per device, under a lock: the first flagged call of a process synchronises with the device, the later ones do not)
         static uint32_t* shared_pace[64] = {};
+        static std::mutex shared_pace_lock;
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64) return fail(MCQ_EDEVICE, "device ordinal out of range");
-        if (!shared_pace[dev]) {
-            HIP_TRY(hipMalloc((void**)&shared_pace[dev], PACE_BYTES));
-            HIP_TRY(hipMemset(shared_pace[dev], 0, PACE_BYTES));
+        {
+            std::lock_guard<std::mutex> guard(shared_pace_lock);
+            if (!shared_pace[dev]) {
+                uint32_t* t = nullptr;
+                HIP_TRY(hipMalloc((void**)&t, PACE_BYTES));
+                if (hipMemset(t, 0, PACE_BYTES) != hipSuccess) {
+                    (void)hipFree(t);
+                    return fail(MCQ_EDEVICE, "hipMemset of the shared progress table failed");
+                }
+                shared_pace[dev] = t;
+            }
+            a.pace = shared_pace[dev];
         }
-        a.pace = shared_pace[dev];
     } else {
         HIP_TRY(hipMemsetAsync(a.pace, 0, PACE_BYTES, s));
     }
