@@ -81,3 +81,44 @@ def test_summary_arithmetic_survives_large_counts():
     assert s["min_best"] == 25 and s["mean_best"] == best and abs(s["std_best"] - 2.0) < 1e-12 and s["mean_steps_to_best"] == 900000
     huge = np.array([2**31 - 1, 0, 0, (2**31 - 1) * 14000, (2**31 - 1) * 14000**2, 0], dtype=np.int64)
     assert dm.summary_from_counters(huge, np.array([1], dtype=np.int64))["std_best"] == 0.0
+
+
+def _table_worker(rank, world, port, q):
+    import importlib.util
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        t = bench.per_rank_table(torch, dist, rank, world, torch.device("cpu"), {"sweep_ms": 100.0 + rank, "reduce_ms": 0.5 * (rank + 1)})
+        q.put((rank, t))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_per_rank_table_of_the_bench_line_on_two_gloo_ranks():
+    """What bench.py prints for reading an N > 1 run afterwards: every rank's own times side by side, identical on every rank."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_table_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == {"reduce_ms": [0.5, 1.0], "sweep_ms": [100.0, 101.0]}
