@@ -247,6 +247,26 @@ int mcq_trace_stats_device(const mcq_params* p, const mcq_outputs* out, int64_t*
                            uint64_t* bin_proposed, void* hip_stream);
 
 /*
+ * The node-level summary of a finished launch, packed for the ONE all-reduce of a job list (the layout of the host side's
+ * distributed.py): replaces the per-run gathering of run_experiment (experiments.py:519-546) and the statistics the drivers take from it
+ * (experiments.py:1074-1096) with one or two small kernels per launch, where the host side needed ~10 tensor operations per job.
+ * One mcq_pack_slot per schedule set of the launch (n_sets <= 1: one) says where that job's fields sit in `packed` (word offsets; -1 = absent).
+ * The set's chains on this rank are [t * chains_per_set, t * chains_per_set + n_local).  `packed` must have been zeroed; the call WRITES the
+ * counters and slots of its jobs (other ranks' shares arrive by the all-reduce) and adds to the stopped-chain histogram.
+ * `out` holds the DEVICE buffers mcq_run_device filled (hist_len, steps_executed, best_energy, steps_to_best, n_accepted; with a stats offset
+ * the four step_* arrays of trace == REDUCED).  Enqueued on `hip_stream`; asynchronous.
+ */
+typedef struct mcq_pack_slot {
+    int64_t counters; /* 6 words: chains, accepted, proposed, sum of best_energy, sum of its squares, sum of steps_to_best */
+    int64_t min_slot; /* this rank's slot of the per-rank minima: min(best_energy) + 1 (0 = the rank holds no chain of the job) */
+    int64_t best;     /* first of the n_local per-chain slots of best_energy (already offset to this rank's first chain), or -1 */
+    int64_t stb;      /* the same for steps_to_best, or -1 */
+    int64_t stats;    /* first of 5 x (n_steps + 1) words: per-entry sum, sum of squares, accepted, count, chains that stopped early at the entry; or -1 */
+} mcq_pack_slot;
+int mcq_pack_summary_device(const mcq_params* p, const mcq_outputs* out, int64_t n_local, const mcq_pack_slot* slots /* HOST, one per set */,
+                            int64_t* packed /* DEVICE */, void* hip_stream);
+
+/*
  * The beta(step) table the sweep reads (experiments.py:13-77 evaluated on the device in float64, strict IEEE):
  * `beta_out` is a DEVICE buffer of double[n_sets][n_steps] (n_sets <= 1: [n_steps]); `c32_out` (optional, DEVICE,
  * float, same shape) receives (float)(-beta * log2(e)), the factor of the float32 accept bracket.  Inspection /

@@ -152,6 +152,8 @@ def lib():
         L.mcq_trace_stats_device.restype = C.c_int
         L.mcq_trace_stats_device.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Outputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_pack_summary_device.restype = C.c_int
+        L.mcq_pack_summary_device.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Outputs), C.c_int64, C.POINTER(abi.PackSlot), C.c_void_p, C.c_void_p]
         L.mcq_beta_table_device.restype = C.c_int
         L.mcq_beta_table_device.argtypes = [C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_run_host.restype = C.c_int

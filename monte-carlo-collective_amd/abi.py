@@ -82,6 +82,11 @@ class Params(C.Structure):
     ]
 
 
+class PackSlot(C.Structure):
+    """include/mcq.h: mcq_pack_slot -- where one job's fields sit in the packed summary tensor (word offsets, -1 = absent)"""
+    _fields_ = [("counters", C.c_int64), ("min_slot", C.c_int64), ("best", C.c_int64), ("stb", C.c_int64), ("stats", C.c_int64)]
+
+
 class Outputs(C.Structure):
     _fields_ = [
         ("energy_hist", C.c_void_p),

@@ -2068,6 +2068,66 @@ __global__ __launch_bounds__(256) void mcq_accept_bins_kernel(const unsigned lon
 }
 
 // ------------------------------------------------------------------------------------------------
+// the packed node summary of a launch (mcq_pack_summary_device): one workgroup per schedule set reduces the set's chains on this rank
+// and fills its job's counters, minimum slot and per-chain slots; a second kernel copies the four per-entry arrays of the reduced trace.
+// ------------------------------------------------------------------------------------------------
+constexpr int PACK_SETS = 32;  // slots per launch of the pack kernels (more sets: several launches)
+struct PackArgs {
+    mcq_pack_slot slot[PACK_SETS];
+    const int32_t* best;
+    const int64_t *stb, *acc, *exe, *hist_len;
+    const int64_t *step_sum, *step_sumsq, *step_accepted, *step_count;
+    long long cps, n_local, n_steps, first_set;
+    int64_t* packed;
+};
+
+__global__ __launch_bounds__(256) void mcq_pack_kernel(PackArgs a) {
+    __shared__ long long red[6][256];
+    const mcq_pack_slot sl = a.slot[blockIdx.x];
+    const long long c0 = (a.first_set + blockIdx.x) * a.cps;
+    long long s_acc = 0, s_exe = 0, s_best = 0, s_sq = 0, s_stb = 0, mn = 0x7fffffffffffffffLL;
+    for (long long r = threadIdx.x; r < a.n_local; r += 256) {
+        const long long be = a.best[c0 + r], sb = a.stb[c0 + r];
+        s_acc += a.acc[c0 + r], s_exe += a.exe[c0 + r], s_best += be, s_sq += be * be, s_stb += sb;
+        mn = be < mn ? be : mn;
+        if (sl.best >= 0) a.packed[sl.best + r] = be;
+        if (sl.stb >= 0) a.packed[sl.stb + r] = sb;
+        if (sl.stats >= 0) {  // a chain that stopped early did so at the entry it did not append (experiments.py:349-353)
+            const long long hl = a.hist_len[c0 + r];
+            if (hl <= a.n_steps) atomicAdd((unsigned long long*)&a.packed[sl.stats + 4 * (a.n_steps + 1) + hl], 1ull);
+        }
+    }
+    red[0][threadIdx.x] = s_acc, red[1][threadIdx.x] = s_exe, red[2][threadIdx.x] = s_best, red[3][threadIdx.x] = s_sq, red[4][threadIdx.x] = s_stb, red[5][threadIdx.x] = mn;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            for (int k = 0; k < 5; k++) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+            red[5][threadIdx.x] = red[5][threadIdx.x + o] < red[5][threadIdx.x] ? red[5][threadIdx.x + o] : red[5][threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int64_t* c = a.packed + sl.counters;
+        c[0] = a.n_local;
+        if (a.n_local > 0) {
+            c[1] = red[0][0], c[2] = red[1][0], c[3] = red[2][0], c[4] = red[3][0], c[5] = red[4][0];
+            a.packed[sl.min_slot] = red[5][0] + 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mcq_pack_stats_kernel(PackArgs a) {
+    const mcq_pack_slot sl = a.slot[blockIdx.y];
+    if (sl.stats < 0) return;
+    const long long L = a.n_steps + 1, e = (long long)blockIdx.x * 256 + threadIdx.x, src = (a.first_set + blockIdx.y) * L + e;
+    if (e >= L) return;
+    a.packed[sl.stats + e] = a.step_sum[src];
+    a.packed[sl.stats + L + e] = a.step_sumsq[src];
+    a.packed[sl.stats + 2 * L + e] = a.step_accepted[src];
+    a.packed[sl.stats + 3 * L + e] = a.step_count[src];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512];
@@ -2792,6 +2852,37 @@ int mcq_trace_stats_device(const mcq_params* p, const mcq_outputs* out, int64_t*
             HIP_TRY(hipGetLastError());
         }
     }
+    return MCQ_OK;
+}
+
+int mcq_pack_summary_device(const mcq_params* p, const mcq_outputs* out, int64_t n_local, const mcq_pack_slot* slots, int64_t* packed, void* hip_stream) {
+    int rc = validate(p);
+    if (rc != MCQ_OK) return rc;
+    if (!out || !slots || !packed) return fail(MCQ_EINVAL, "null argument");
+    if (!out->best_energy || !out->steps_to_best || !out->n_accepted || !out->steps_executed || !out->hist_len)
+        return fail(MCQ_EINVAL, "the packed summary needs best_energy, steps_to_best, n_accepted, steps_executed and hist_len");
+    const long long sets = (long long)n_sets_of(p), cps = p->n_sets > 1 ? p->chains_per_set : p->n_chains;
+    if (n_local < 0 || n_local > cps) return fail(MCQ_EINVAL, "n_local out of range");
+    bool stats = false;
+    for (long long t = 0; t < sets; t++) {
+        if (slots[t].counters < 0 || slots[t].min_slot < 0) return fail(MCQ_EINVAL, "a pack slot needs its counters and its minimum slot");
+        stats |= slots[t].stats >= 0;
+    }
+    if (stats && (p->trace != MCQ_TRACE_REDUCED || !out->step_sum || !out->step_sumsq || !out->step_accepted || !out->step_count))
+        return fail(MCQ_EINVAL, "per-entry statistics are packed from the reduced trace (trace == REDUCED with its four step_* arrays)");
+    hipStream_t s = (hipStream_t)hip_stream;
+    for (long long t0 = 0; t0 < sets; t0 += PACK_SETS) {
+        PackArgs a;
+        memset(&a, 0, sizeof a);
+        const int n = (int)(sets - t0 < PACK_SETS ? sets - t0 : PACK_SETS);
+        for (int k = 0; k < n; k++) a.slot[k] = slots[t0 + k];
+        a.best = out->best_energy, a.stb = out->steps_to_best, a.acc = out->n_accepted, a.exe = out->steps_executed, a.hist_len = out->hist_len;
+        a.step_sum = out->step_sum, a.step_sumsq = out->step_sumsq, a.step_accepted = out->step_accepted, a.step_count = out->step_count;
+        a.cps = cps, a.n_local = n_local, a.n_steps = p->n_steps, a.first_set = t0, a.packed = packed;
+        hipLaunchKernelGGL(mcq_pack_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
+        if (stats) hipLaunchKernelGGL(mcq_pack_stats_kernel, dim3((unsigned)((p->n_steps + 1 + 255) / 256), (unsigned)n), dim3(256), 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
 

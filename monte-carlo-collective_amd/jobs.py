@@ -142,6 +142,7 @@ class _Launch:
     def __init__(self, job_ids, run, n_local, cps):
         self.job_ids, self.run, self.n_local, self.cps = job_ids, run, n_local, cps
         self.stream = None
+        self.pack_slots = None
         self.priority = 0
         self.no_stops = None  # a zero step_stopped array, shared by the launch's jobs when none of its chains can stop early
 
@@ -345,6 +346,17 @@ class JobSet:
             for la in self.launches:
                 la.stream.synchronize()
 
+    def _pack_slots(self, la):
+        """include/mcq.h: mcq_pack_slot per schedule set of the launch -- where its job's fields sit in the packed tensor."""
+        arr = (abi.PackSlot * len(la.job_ids))()
+        for s, i in enumerate(la.job_ids):
+            lay, lo = self.layouts[i], self.shards[i][1]
+            arr[s].counters, arr[s].min_slot = lay.counters, lay.mins + self.rank
+            arr[s].best = lay.best + lo if lay.per_chain else -1
+            arr[s].stb = lay.stb + lo if lay.per_chain else -1
+            arr[s].stats = lay.stat0 if lay.stats else -1
+        return arr
+
     def _local_views(self):
         """Per job: this rank's result tensors (views into the launches' output buffers)."""
         torch = self.torch
@@ -402,14 +414,29 @@ class JobSet:
         Lifetime of the returned arrays (GPU path): they are NumPy VIEWS of one of two page-locked host buffers this JobSet owns and
         uses in turn -- valid through the NEXT reduce() of this JobSet, overwritten by the one after, and pinned memory stays
         allocated while the JobSet (or any result array) lives.  Copy what must outlive two reduces."""
+        native = self.runner is None and os.environ.get("MCQ_PACK", "native") != "torch"
         if self.runner is None:
             torch = self.torch
             cur = torch.cuda.current_stream()
             for la in self.launches:  # everything below runs on the current stream, behind every launch
                 cur.wait_stream(la.stream)
-            torch_views = self._local_views()
             buf = self.buf
             buf.zero_()
+            if native:
+                # One or two small kernels per launch (mcq_pack_summary_device) instead of ~10 tensor operations per job: 54 jobs of
+                # measure_min_energy_vs_N were ~400 tiny kernels, 6.5 ms behind a 180 ms sweep (profiles/r04_shapes.txt).
+                import ctypes as C
+
+                from . import _lib
+
+                L = _lib.lib()
+                for la in self.launches:
+                    if la.pack_slots is None:
+                        la.pack_slots = self._pack_slots(la)
+                    _lib._check(L.mcq_pack_summary_device(C.byref(la.run.p), C.byref(la.run.out), la.n_local, la.pack_slots, buf.data_ptr(), C.c_void_p(cur.cuda_stream)))
+                torch_views = None
+            else:
+                torch_views = self._local_views()
         else:
             torch_views = self._injected_views()
             torch = self.torch
@@ -418,7 +445,7 @@ class JobSet:
                 dev = torch.device("cuda", torch.cuda.current_device())
             buf = torch.zeros(self.total_words, dtype=torch.int64, device=dev)
         empty = torch.zeros(0, dtype=torch.int64, device=buf.device)
-        for i, lay in enumerate(self.layouts):
+        for i, lay in enumerate(self.layouts if torch_views is not None else ()):
             r = torch_views[i]
             if r is None:
                 zeros = {k: torch.zeros(lay.n_steps + 1, dtype=torch.int64, device=buf.device) for k in dm.STAT_FIELDS} if lay.stats else {}
