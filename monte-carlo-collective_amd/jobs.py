@@ -311,17 +311,22 @@ class JobSet:
 
     def close(self):
         """Release the CU-masked HIP streams of this JobSet (torch does not own external streams).  Called on garbage collection too."""
-        from . import _lib
+        masked, self._masked = getattr(self, "_masked", []), []
+        if not masked:
+            return
+        try:
+            from . import _lib
 
-        for h in getattr(self, "_masked", []):
-            try:
+            for h in masked:
                 _lib.destroy_stream(h)
-            except Exception:  # interpreter shutdown: the runtime may be gone already
-                pass
-        self._masked = []
+        except Exception:  # interpreter shutdown: the import machinery or the runtime may be gone already
+            pass
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def launch(self):
         """Enqueue every launch on its stream; returns immediately (GPU path) or after the injected runner has run."""

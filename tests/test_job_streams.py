@@ -43,3 +43,30 @@ def test_pacing_priorities_and_cu_layers_change_nothing(monkeypatch):
     assert got == ref and st[0] == "shared" and not st[1]
     got, st = _run(monkeypatch, MCQ_CU_PARTITION="1", MCQ_JOB_PACING="0", MCQ_JOB_PRIORITY="0")
     assert got == ref and st[1]
+
+
+@pytest.mark.parametrize("want", ["summary", "stats", "histories"])
+def test_native_pack_equals_the_tensor_operations(monkeypatch, want):
+    """mcq_pack_summary_device (one or two small kernels per launch) against the same packing done with tensor operations (distributed.pack_job):
+    counters, per-rank minima, per-chain slots, the four per-entry arrays of the reduced trace and the stopped-chain histogram of early stops."""
+    jobs = [jb.make_job(8, 400, "random", SP, 48, 11, "board", 60), jb.make_job(8, 400, "latin", {"type": "constant", "beta_const": 2.0}, 48, 99, "board", 60),
+            jb.make_job(12, 300, "random", SP, 37, 5, "board", None), jb.make_job(9, 200, "random", SP, 16, 3, "full_3d", None)]
+    out = {}
+    for mode in ("torch", "native"):
+        monkeypatch.setenv("MCQ_PACK", mode)
+        js = jb.JobSet(jobs, want=want)
+        res = js.run()
+        out[mode] = [{k: (np.array(v).copy() if not isinstance(v, dict) else dict(v)) for k, v in r.items()} for r in res]
+        js.close()
+    for a, b in zip(out["torch"], out["native"]):
+        assert a.keys() == b.keys()
+        for k in a:
+            if isinstance(a[k], dict):
+                assert a[k] == b[k], k
+            elif k == "energy_hist":  # (rows of chains that stopped early hold nothing defined behind their last entry)
+                for r, n in enumerate(a["hist_len"]):
+                    np.testing.assert_array_equal(a[k][r, :n], b[k][r, :n], err_msg=f"{k}[{r}]")
+            else:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    if want == "stats":
+        assert out["native"][0]["step_stopped"].sum() > 0  # chains of the early-stop jobs did stop
