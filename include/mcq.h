@@ -84,10 +84,12 @@ extern "C" {
 #define MCQ_FLAG_PRIORITY(p) (((uint32_t)(p) & 3u) << MCQ_FLAG_PRIORITY_SHIFT)
 
 /* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319; the reference itself is
- * unbounded).  full_3d: column occupancy is one 32-bit word per column.  board: bit masks up to N = 32, a compare per probed
+ * unbounded).  full_3d: column occupancy is one word per column -- 16 bits up to N = 16, 32 up to N = 32, 64 up to N = 64 (that variant:
+ * 16 lanes per chain, NumPy's stream, no replica exchange; the queen table and the N^3 cells np.random.choice permutes live in the
+ * workspace: N^3 * 4 bytes for each of at most 256 chains at a time).  board: bit masks up to N = 32, a compare per probed
  * height beyond (slower, any size whose N*N heights fit a wavefront's share of the LDS and whose accept flags fit a byte). */
 #define MCQ_MIN_N 2
-#define MCQ_MAX_N 32        /* mcmc_type full_3d */
+#define MCQ_MAX_N 64        /* mcmc_type full_3d (beyond 32: 64-bit column words, 16 lanes per chain) */
 #define MCQ_MAX_N_BOARD 128 /* mcmc_type board */
 
 /* One set of a batched run: its beta schedule (run_beta_start_end_pairs loops over such pairs: experiments.py:741-846) and,
@@ -195,8 +197,8 @@ int mcq_abi_version(void);
 const char* mcq_last_error(void);
 int mcq_device_count(void);
 
-/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 12 and 8 beyond, full_3d 8
- * (mcq_default_lanes: the value for small boards).  A board launch that leaves SIMDs empty runs at twice or four times the
+/* lanes of a wavefront per chain used when mcq_params.lanes_per_chain == 0: board 4 up to N = 12 and 8 beyond, full_3d 8 (16 beyond
+ * N = 32, the only width of that variant; 4 for N = 9..12 with NumPy's stream) (mcq_default_lanes: the value for small boards).  A board launch that leaves SIMDs empty runs at twice or four times the
  * lanes while every wavefront still has a SIMD to itself (N >= 20: at most 8; N <= 8: always 4); with replica exchange a ladder must fit one
  * wavefront.  mcq_effective_lanes tells.  The lane count never changes a result. */
 int32_t mcq_default_lanes(int32_t mode);

@@ -36,7 +36,7 @@ def flag_priority(p):
     return (int(p) & 3) << FLAG_PRIORITY_SHIFT
 
 
-MIN_N, MAX_N, MAX_N_BOARD = 2, 32, 128  # include/mcq.h: full_3d up to 32, boards up to 128
+MIN_N, MAX_N, MAX_N_BOARD = 2, 64, 128  # include/mcq.h: full_3d up to 64, boards up to 128
 MAX_HIST_STRIDE = 1 << 24  # a full trace row (hist_stride entries) must stay below this: include/mcq.h
 
 

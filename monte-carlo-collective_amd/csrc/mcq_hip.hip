@@ -155,7 +155,9 @@ struct KArgs {
     const double* exch_ladder;  // [exch_R] beta multipliers per rung (workspace)
     int dry;                  // launch_sweep: check that the chosen variant fits the device and return without launching
     uint16_t* qtab;           // full_3d: the queens of every chain as i | j << 5 | k << 10, [n_chains][qtab_stride] (workspace; the sweep variants that
-    int qtab_stride;          // keep their queen table out of LDS work on it, the init kernel fills it)
+    int qtab_stride;          // keep their queen table out of LDS work on it, the init kernel fills it).  Beyond N = 32: uint32 entries i | j << 8 | k << 16
+    uint32_t* perm;           // full_3d beyond N = 32, random init: the N^3 cells np.random.choice permutes, one slice per chain of an init launch (workspace)
+    long long chain0;         // init kernel: first chain of this launch (the launches of one run share the `perm` slices)
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int L = 64 / CI;
     const int lane = threadIdx.x, sub = lane & (L - 1), grp = lane / L;
-    const long long mine = (long long)blockIdx.x * CI + grp;
+    const long long slot = (long long)blockIdx.x * CI + grp, mine = a.chain0 + slot;
     const bool valid = mine < a.n_chains;
     const long long chain = valid ? mine : a.n_chains - 1;  // (an idle group repeats the last chain in its own LDS slice and writes nothing)
     const int N = a.N, Q = a.Q;
@@ -451,15 +453,32 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
             // np.random.choice(N^3, Q, replace=False) = permutation(N^3)[:Q]: identity array, then for
             // t = n-1 .. 1 swap(arr[t], arr[bounded(t)]) (mcmc.py:97); cells decoded k fastest.
             const int n = N * N * N;
-            for (int t = sub; t < n; t += L) perm[t] = (uint16_t)t;
-            for (int t = n - 1; t >= 1; t--) {
-                const int s = rng.bounded((unsigned)t, mask_for((unsigned)t));
-                const uint16_t at = perm[t], as = perm[s];
-                if (sub == 0) perm[t] = as, perm[s] = at;
-            }
-            for (int c = sub; c < Q; c += L) {
-                const int f = perm[c];
-                st[3 * c] = (uint8_t)(f / (N * N)), st[3 * c + 1] = (uint8_t)((f / N) % N), st[3 * c + 2] = (uint8_t)(f % N);
+            if (a.perm) {
+                // beyond N = 32 the cells no longer fit LDS (nor, from N = 41, 16 bits): the array lives in global memory, a slice per
+                // chain of this launch.  Every lane of the chain reads the two entries of a swap (one request), its first lane writes them;
+                // a wavefront's accesses to one address stay in program order.  ~1.5 us per swap: N = 64 takes 0.4 s, once per run.
+                uint32_t* gp = a.perm + slot * (long long)n;
+                for (int t = sub; t < n; t += L) gp[t] = (uint32_t)t;
+                for (int t = n - 1; t >= 1; t--) {
+                    const int s = rng.bounded((unsigned)t, mask_for((unsigned)t));
+                    const uint32_t at = gp[t], as = gp[s];
+                    if (sub == 0) gp[t] = as, gp[s] = at;
+                }
+                for (int c = sub; c < Q; c += L) {
+                    const int f = (int)gp[c];
+                    st[3 * c] = (uint8_t)(f / (N * N)), st[3 * c + 1] = (uint8_t)((f / N) % N), st[3 * c + 2] = (uint8_t)(f % N);
+                }
+            } else {
+                for (int t = sub; t < n; t += L) perm[t] = (uint16_t)t;
+                for (int t = n - 1; t >= 1; t--) {
+                    const int s = rng.bounded((unsigned)t, mask_for((unsigned)t));
+                    const uint16_t at = perm[t], as = perm[s];
+                    if (sub == 0) perm[t] = as, perm[s] = at;
+                }
+                for (int c = sub; c < Q; c += L) {
+                    const int f = perm[c];
+                    st[3 * c] = (uint8_t)(f / (N * N)), st[3 * c + 1] = (uint8_t)((f / N) % N), st[3 * c + 2] = (uint8_t)(f % N);
+                }
             }
         }
     }
@@ -525,8 +544,13 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     uint8_t* rst = (uint8_t*)(rec + REC_STATE);
     for (int c = sub; c < a.state_bytes; c += L) rst[c] = st[c];
     if (a.mode == MCQ_MODE_FULL3D && a.qtab) {
-        uint16_t* qt = a.qtab + chain * (long long)a.qtab_stride;
-        for (int c = sub; c < Q; c += L) qt[c] = (uint16_t)(st[3 * c] | (st[3 * c + 1] << 5) | (st[3 * c + 2] << 10));
+        if (N > 32) {
+            uint32_t* qt = (uint32_t*)a.qtab + chain * (long long)a.qtab_stride;
+            for (int c = sub; c < Q; c += L) qt[c] = (uint32_t)st[3 * c] | ((uint32_t)st[3 * c + 1] << 8) | ((uint32_t)st[3 * c + 2] << 16);
+        } else {
+            uint16_t* qt = a.qtab + chain * (long long)a.qtab_stride;
+            for (int c = sub; c < Q; c += L) qt[c] = (uint16_t)(st[3 * c] | (st[3 * c + 1] << 5) | (st[3 * c + 2] << 10));
+        }
     }
 }
 
@@ -987,6 +1011,13 @@ __device__ __forceinline__ void copy_board_out(uint8_t* dst, const uint8_t* hts,
 }
 // full_3d: queens are packed i | j << 5 | k << 10 in LDS and (i, j, k) bytes in the caller's row: four queens = three dwords
 template <int G>
+__device__ __forceinline__ void copy_queens_out(uint8_t* dst, const uint32_t* qn, int Q, int gl) {  // beyond N = 32: i | j << 8 | k << 16
+    for (int c = gl; c < Q; c += G) {
+        const uint32_t pq = qn[c];
+        dst[3 * c] = (uint8_t)pq, dst[3 * c + 1] = (uint8_t)(pq >> 8), dst[3 * c + 2] = (uint8_t)(pq >> 16);
+    }
+}
+template <int G>
 __device__ __forceinline__ void copy_queens_out(uint8_t* dst, const uint16_t* qn, int Q, int gl) {
     if ((Q & 3) == 0) {
         for (int c = gl; c < (Q >> 2); c += G) {
@@ -1012,10 +1043,10 @@ __device__ __forceinline__ void copy_queens_out(uint8_t* dst, const uint16_t* qn
 // copies of these loops and spill; a call in the rare improvement path costs them nothing measurable and frees ~15 VGPRs.
 template <int G>
 __device__ __attribute__((noinline)) void copy_board_out_call(uint8_t* dst, const uint8_t* hts, int Q, int gl) { copy_board_out<G>(dst, hts, Q, gl); }
-template <int G>
-__device__ __attribute__((noinline)) void copy_queens_out_call(uint8_t* dst, const uint16_t* qn, int Q, int gl) { copy_queens_out<G>(dst, qn, Q, gl); }
-template <int MODE, int G, bool CALL>
-__device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts, const uint16_t* qn, int Q, int gl) {
+template <int G, typename QN>
+__device__ __attribute__((noinline)) void copy_queens_out_call(uint8_t* dst, const QN* qn, int Q, int gl) { copy_queens_out<G>(dst, qn, Q, gl); }
+template <int MODE, int G, bool CALL, typename QN>
+__device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts, const QN* qn, int Q, int gl) {
     if constexpr (MODE == MCQ_MODE_BOARD) {
         if constexpr (CALL) copy_board_out_call<G>(dst, hts, Q, gl);
         else copy_board_out<G>(dst, hts, Q, gl);
@@ -1055,7 +1086,10 @@ __device__ __forceinline__ void copy_state_out(uint8_t* dst, const uint8_t* hts,
 // line index is linear in (i, j, k); lane gl of a chain owns the families gl, gl + 4, gl + 8: three counters read for the old cell,
 // three for the new one, and an accepted move writes those six back (+-1) -- 2 N^2 + 6 N (2N - 1) + 4 (2N - 1)^2 bytes per chain
 // (N = 8: 1 748, N = 4: 396), which is what keeps this a variant for small boards (profiles/r04_line_counters.txt).
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false, bool CNT = false>
+// WIDE (full_3d beyond N = 32, run-time probe loop, 16 lanes per chain): 64-bit column words (N = 64: 32 KB per chain, four chains per
+// wavefront), and the queens -- i | j << 8 | k << 16 in 32-bit entries -- stay in the workspace's table like SLIM's.
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false, bool CNT = false,
+          bool WIDE = false>
 #ifndef MCQ_EXP_WAVES  // experiment (profiles/r03_occupancy5.txt): the register budget of more wavefronts per SIMD
 #define MCQ_EXP_WAVES 4
 #endif
@@ -1065,6 +1099,7 @@ template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = fa
 #endif
 __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3D && G == 4 && NT > 0 && !SLIM) ? 2 : (SLIM && NT > 6) ? 3 : MCQ_EXP_WAVES) void mcq_sweep_kernel(KArgs a) {
     static_assert(!SLIM || (MODE == MCQ_MODE_FULL3D && NT > 0 && !PATIENCE), "the slim layout exists for the unrolled full_3d kernels");
+    static_assert(!WIDE || (MODE == MCQ_MODE_FULL3D && NT == 0 && NC == 0 && G == 16 && !SLIM), "64-bit column words: the run-time-loop full_3d kernel at 16 lanes per chain");
     static_assert(!CNT || (MODE == MCQ_MODE_BOARD && G == 4 && NT == 0 && !EXCH), "line counters: boards at 4 lanes per chain");
     static_assert(G >= 4 || MODE == MCQ_MODE_BOARD, "two lanes per chain: boards only (full_3d splits a chain's lanes between two cells)");
     static_assert(!EXCH || (!PATIENCE && !REDUCED), "replica exchange runs without early stop and with trace none / i32");
@@ -1101,11 +1136,15 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
     // full_3d: colw[i*N+j] = occupancy word of column (i,j) (bit k set: a queen at (i,j,k)), padded on either
     // side for the out-of-board diagonal probes; qn[q] = queen q as i | j<<5 | k<<10
     constexpr bool NARROW = MODE == MCQ_MODE_FULL3D && NT > 0;  // N <= 16: 16-bit column words
-    typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type colw_t;
+    typedef typename std::conditional<WIDE, uint64_t, typename std::conditional<NARROW, uint16_t, uint32_t>::type>::type colw_t;
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type cword_t;  // a column word in a register
+    typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type qn_t;     // a queen: i | j << QS | k << 2 QS
+    constexpr int QS = WIDE ? 8 : 5;
+    constexpr uint32_t QM = WIDE ? 63u : 31u;
     colw_t* colw = (colw_t*)(base + L_STATE) + full_pad;
-    uint16_t* const qn = [&]() {
-        if constexpr (SLIM) return a.qtab + crow * (long long)a.qtab_stride;  // global memory, filled by the init kernel
-        else return (uint16_t*)(colw + NN + full_pad);
+    qn_t* const qn = [&]() {
+        if constexpr (SLIM || WIDE) return (qn_t*)a.qtab + crow * (long long)a.qtab_stride;  // global memory, filled by the init kernel
+        else return (qn_t*)(colw + NN + full_pad);
     }();
 
     // ---- load the chain record ----
@@ -1146,9 +1185,10 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
         for (int w = gl; w < cwords; w += G) cw32[w] = 0;
         for (int c = gl; c < Q; c += G) {
             const uint32_t qi_ = rst[3 * c], qj_ = rst[3 * c + 1], qk_ = rst[3 * c + 2];
-            if constexpr (!SLIM) qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
+            if constexpr (!SLIM && !WIDE) qn[c] = (uint16_t)(qi_ | (qj_ << 5) | (qk_ << 10));
             const uint32_t e = (uint32_t)full_pad + qi_ * N + qj_;  // element index from the start of the table
-            if (NARROW) atomicOr(&cw32[e >> 1], (1u << qk_) << ((e & 1u) * 16u));
+            if constexpr (WIDE) atomicOr((unsigned long long*)cw32 + e, 1ull << qk_);
+            else if (NARROW) atomicOr(&cw32[e >> 1], (1u << qk_) << ((e & 1u) * 16u));
             else atomicOr(&cw32[e], 1u << qk_);
         }
     }
@@ -1520,8 +1560,11 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
 #else
                 oldp = qn[qi];
 #endif
-                pa = (int)(w1 & maskN), pb = (int)(w2 & maskN), pc = (int)(w3 & maskN) & 31;
-                const uint32_t cw1 = colw[__mul24(pa, N) + pb];  // word index < 2^10: inside the workgroup's LDS
+                pa = (int)(w1 & maskN), pb = (int)(w2 & maskN), pc = (int)((w3 & maskN) & QM);
+                // (WIDE: an attempt that is not used may hold any value up to the mask, 63 -- at N = 33 a column index far behind the chain's table,
+                // and for the wavefront's last chain behind the workgroup's LDS: clamped, here and for the other two triples)
+                if constexpr (WIDE) pa = min(pa, (int)mN), pb = min(pb, (int)mN);
+                const cword_t cw1 = colw[__mul24(pa, N) + pb];  // word index < 2^10 (WIDE: 2^12): inside the workgroup's LDS
                 const bool free1 = !((cw1 >> pc) & 1u);
                 int pu = p3;
                 uint32_t third = free1 ? (uint32_t)p3 : 0xffffffffu;
@@ -1535,8 +1578,10 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                     const uint32_t n4 = n3 & (n3 - 1), n5 = n4 & (n4 - 1), n6 = n5 & (n5 - 1);
                     const int p4 = lowest_bit(n4), p5 = lowest_bit(n5), p6 = lowest_bit(n6 & 0x3fffffffu);
                     const uint32_t w4 = rd(p4), w5 = rd(p5), w6 = rd(p6);
-                    const int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN), k2 = (int)(w6 & maskN) & 31;
-                    const uint32_t cw2 = colw[__mul24(i2, N) + j2];
+                    int i2 = (int)(w4 & maskN), j2 = (int)(w5 & maskN);
+                    const int k2 = (int)((w6 & maskN) & QM);
+                    if constexpr (WIDE) i2 = min(i2, (int)mN), j2 = min(j2, (int)mN);
+                    const cword_t cw2 = colw[__mul24(i2, N) + j2];
                     // (a position counts only when its word has been generated; nothing does under MCQ_FLAG_SEQUENTIAL_DRAWS)
                     const uint32_t availm = avail & batch_mask;
                     const bool valid3 = (uint32_t)p3 < availm, valid6 = (uint32_t)p6 < availm, taken2 = ((cw2 >> k2) & 1u) != 0;
@@ -1557,8 +1602,10 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                         const uint32_t n7 = n6 & (n6 - 1), n8 = n7 & (n7 - 1), n9 = n8 & (n8 - 1);
                         const int p7 = lowest_bit(n7), p8 = lowest_bit(n8), p9 = lowest_bit(n9 & 0x3fffffffu);
                         const uint32_t w7 = rd(p7), w8 = rd(p8), w9 = rd(p9);
-                        const int i3 = (int)(w7 & maskN), j3 = (int)(w8 & maskN), k3 = (int)(w9 & maskN) & 31;
-                        const uint32_t cw3 = colw[__mul24(i3, N) + j3];
+                        int i3 = (int)(w7 & maskN), j3 = (int)(w8 & maskN);
+                        const int k3 = (int)((w9 & maskN) & QM);
+                        if constexpr (WIDE) i3 = min(i3, (int)mN), j3 = min(j3, (int)mN);
+                        const cword_t cw3 = colw[__mul24(i3, N) + j3];
                         const bool look3 = both && (uint32_t)p9 < availm, taken3 = ((cw3 >> k3) & 1u) != 0;
                         const bool use3 = look3 && !taken3;
                         const bool third_ok = use3 && (uint32_t)p9 < draw_limit;
@@ -1600,7 +1647,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             // ---- dE -------------------------------------------------------------------------------
             int dE;
             uint32_t newp = 0;
-            uint32_t cw_new = 0, cw_old = 0;  // full_3d: occupancy words of the new and of the old cell's column
+            cword_t cw_new = 0, cw_old = 0;  // full_3d: occupancy words of the new and of the old cell's column
             int cix[6] = {0, 0, 0, 0, 0, 0};  // CNT: the lane's three old-cell and three new-cell lines ...
             int cvl[6] = {0, 0, 0, 0, 0, 0};  // ... and their counts, kept for the write-back of an accepted move
             if constexpr (CNT) {
@@ -1705,19 +1752,23 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 // four lines of the ij-plane through (ci,cj) at distance d, the heights ck and ck +- d.  With W the
                 // occupancy word of that column, the attackers in it are popc(W & (B | B<<d | B>>d)), B = 1<<ck.
                 const int ni = pa, nj = pb, nk = pc;
-                const int oi = oldp & 31, oj = (oldp >> 5) & 31, ok_ = (oldp >> 10) & 31;
-                newp = (uint32_t)ni | ((uint32_t)nj << 5) | ((uint32_t)nk << 10);
-                const uint32_t Bo = 1u << ok_, Bn = 1u << nk;
-                auto star = [&](int m, bool in_board, int ci, int cj, uint32_t B) {
+                const int oi = oldp & QM, oj = (oldp >> QS) & QM, ok_ = (oldp >> (2 * QS)) & QM;
+                newp = (uint32_t)ni | ((uint32_t)nj << QS) | ((uint32_t)nk << (2 * QS));
+                const cword_t Bo = (cword_t)1 << ok_, Bn = (cword_t)1 << nk;
+                auto popc_w = [](cword_t x) -> int {
+                    if constexpr (WIDE) return __popcll(x);
+                    else return __popc(x);
+                };
+                auto star = [&](int m, bool in_board, int ci, int cj, cword_t B) {
                     const int mN_ = __mul24(m, N);
                     const colw_t* cw = colw + mN_;
                     const int jd = m - ci + cj, ja = ci + cj - m;
-                    const uint32_t wr = colw[__mul24(ci, N) + m], wc = cw[cj], wd = cw[jd], wa = cw[ja];
+                    const cword_t wr = colw[__mul24(ci, N) + m], wc = cw[cj], wd = cw[jd], wa = cw[ja];
                     const uint32_t dr = abs_diff(m, cj), dc = abs_diff(m, ci);
-                    const uint32_t Mr = B | (B << dr) | (B >> dr), Mc = B | (B << dc) | (B >> dc);
-                    int c = __popc(wr & Mr) + __popc(wc & Mc);
-                    c += (unsigned)jd < (unsigned)N ? __popc(wd & Mc) : 0;  // out-of-board probes read padding or another column: discarded
-                    c += (unsigned)ja < (unsigned)N ? __popc(wa & Mc) : 0;
+                    const cword_t Mr = B | (B << dr) | (B >> dr), Mc = B | (B << dc) | (B >> dc);
+                    int c = popc_w(wr & Mr) + popc_w(wc & Mc);
+                    c += (unsigned)jd < (unsigned)N ? popc_w(wd & Mc) : 0;  // out-of-board probes read padding or another column: discarded
+                    c += (unsigned)ja < (unsigned)N ? popc_w(wa & Mc) : 0;
                     return in_board ? c : 0;
                 };
                 int part = 0;
@@ -1759,7 +1810,7 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 // new side the moving queen still sits at the old cell; if that lies on a line through the new cell it was
                 // counted and is removed.
                 cw_new = colw[times_N<NC>(ni, N) + nj], cw_old = colw[times_N<NC>(oi, N) + oj];  // kept: an accepted move rewrites them without reading again
-                const int own_new = __popc(cw_new), own_old = __popc(cw_old) - 1;
+                const int own_new = popc_w(cw_new), own_old = popc_w(cw_old) - 1;
                 const int moving = on_a_line_m1(abs_diff_minus_1(oi, ni), abs_diff_minus_1(oj, nj), abs_diff_minus_1(ok_, nk)) ? 1 : 0;
                 dE = group_sum<G>(part) + 4 + own_new - own_old - moving;
             }
@@ -1805,19 +1856,19 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
                 // mcmc.py:171-183; every lane of the group performs the same writes.  The two column words were read for the own-column
                 // counts of dE: no second LDS round trip here.  A move inside one column changes one word twice: the second
                 // store carries both changes (LDS stores of a wavefront land in order).
-                const uint32_t op_i = oldp & 31, op_j = (oldp >> 5) & 31;
-                const uint32_t cleared = cw_old & ~(1u << ((oldp >> 10) & 31));
+                const uint32_t op_i = oldp & QM, op_j = (oldp >> QS) & QM;
+                const cword_t cleared = cw_old & ~((cword_t)1 << ((oldp >> (2 * QS)) & QM));
                 const bool same_column = op_i == (uint32_t)pa && op_j == (uint32_t)pb;
                 colw[times_N<NC>((int)op_i, N) + (int)op_j] = (colw_t)cleared;
-                colw[times_N<NC>(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | (1u << pc));
+                colw[times_N<NC>(pa, N) + pb] = (colw_t)((same_column ? cleared : cw_new) | ((cword_t)1 << pc));
 #if defined(MCQ_EXP_QN_SC1)
                 if constexpr (SLIM) __hip_atomic_store(qn + qi, (uint16_t)newp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else qn[qi] = (uint16_t)newp;
+                else qn[qi] = (qn_t)newp;
 #elif defined(MCQ_EXP_QN_NT)
                 if constexpr (SLIM) __builtin_nontemporal_store((uint16_t)newp, qn + qi);
-                else qn[qi] = (uint16_t)newp;
+                else qn[qi] = (qn_t)newp;
 #else
-                qn[qi] = (uint16_t)newp;
+                qn[qi] = (qn_t)newp;
 #endif
             }
             E += __mul24((int)acc, dE);  // E += acc ? dE : 0  (|dE| <= 8 N)
@@ -2165,7 +2216,12 @@ int validate(const mcq_params* p) {
     if (p->abi_version != MCQ_ABI_VERSION) return fail(MCQ_EINVAL, "abi_version mismatch");
     if (p->mode != MCQ_MODE_BOARD && p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "unknown mcmc_type");
     if (p->N < MCQ_MIN_N || p->N > (p->mode == MCQ_MODE_BOARD ? MCQ_MAX_N_BOARD : MCQ_MAX_N))
-        return fail(MCQ_EINVAL, "N out of range [2, 32] (full_3d) / [2, 128] (board)");
+        return fail(MCQ_EINVAL, "N out of range [2, 64] (full_3d) / [2, 128] (board)");
+    if (p->mode == MCQ_MODE_FULL3D && p->N > 32) {  // the variant with 64-bit column words (mcq_sweep_kernel: WIDE)
+        if (p->lanes_per_chain != 0 && p->lanes_per_chain != 16) return fail(MCQ_EINVAL, "full_3d beyond N = 32 runs at 16 lanes per chain (lanes_per_chain 0 or 16)");
+        if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "full_3d beyond N = 32 runs with NumPy's MT19937 stream only");
+        if (p->exchange_every > 0) return fail(MCQ_EINVAL, "full_3d beyond N = 32 runs without replica exchange");
+    }
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL) return fail(MCQ_EINVAL, "Unknown betta_scheduling type");
     if (p->rng != MCQ_RNG_MT19937_NUMPY && p->rng != MCQ_RNG_PHILOX4X32_10) return fail(MCQ_EINVAL, "unknown rng");
@@ -2226,8 +2282,21 @@ int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_
 int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_of(p) + 3) / 4) + 15) & ~15; }
 #endif
 
-// full_3d: uint16 entries per chain of the packed queen table in the workspace (64-byte rows); 0 for boards
+// full_3d: entries per chain of the packed queen table in the workspace (64-byte rows; uint16 entries, uint32 beyond N = 32); 0 for boards
 int qtab_stride_for(const mcq_params* p) { return p->mode == MCQ_MODE_FULL3D ? (queens_of(p) + 31) & ~31 : 0; }
+size_t qtab_bytes_for(const mcq_params* p) { return (size_t)(p->n_chains > 0 ? p->n_chains : 1) * (size_t)qtab_stride_for(p) * (p->N > 32 ? 4 : 2); }
+// full_3d beyond N = 32 with a random init: the init kernel's permutation arrays (N^3 uint32 per chain) for PERM_SLOTS chains at a time
+constexpr long long PERM_SLOTS = 256;
+bool any_random_init(const mcq_params* p) {
+    bool any = p->init == MCQ_INIT_RANDOM;
+    for (int64_t t = 0; t < p->n_sets && p->n_sets > 1; t++) any |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
+    return any;
+}
+long long perm_slots_for(const mcq_params* p) {
+    if (p->mode != MCQ_MODE_FULL3D || p->N <= 32 || !any_random_init(p)) return 0;
+    return p->n_chains < PERM_SLOTS ? ((p->n_chains > 0 ? p->n_chains : 1) + 3) & ~3LL : PERM_SLOTS;  // (a multiple of the init kernel's chains per wavefront)
+}
+size_t perm_bytes_for(const mcq_params* p) { return (size_t)perm_slots_for(p) * (size_t)p->N * p->N * p->N * 4; }
 
 size_t n_sets_of(const mcq_params* p) { return p->n_sets > 1 ? (size_t)p->n_sets : 1; }
 // one table per schedule set, tab_stride elements apart (a 256-byte multiple for either element size)
@@ -2242,11 +2311,12 @@ constexpr size_t LADDER_BYTES = 16 * 8;       // replica exchange: the beta mult
 
 // LDS words per chain.  board: the diagonal probes read up to N-1 bytes before / after the heights, (N+2)/4 spare words on each
 // side keep those (discarded) reads inside the chain's own slice; full_3d: pad | column words | pad | queens (uint16).
-int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0, bool slim = false, bool counters = false) {
+int chain_lds_words_for(int N, int mode, bool narrow, int Q = 0, bool slim = false, bool counters = false, bool wide = false) {
     const int NN = N * N, pad = (N + 3) & ~3;
     if (Q <= 0) Q = NN;  // full_3d: the queens (mcq_params.n_queens); N * N by default
     int w = LDS_STATE;
     if (mode == MCQ_MODE_BOARD) w += (NN + 3) / 4 + (N + 2) / 4 + (counters ? (2 * NN + 6 * N * (2 * N - 1) + 4 * (2 * N - 1) * (2 * N - 1) + 3) / 4 : 0);
+    else if (wide) w += 2 * (2 * pad + NN);  // WIDE: pad | 64-bit column words | pad; the queens are in global memory
     else if (slim) w = 16 + 4 + RING + (NN + 1) / 2;  // SLIM: stage[16] | cold[4] | ring[64] | 16-bit column words, no pads; the queens are in global memory
     else w += (narrow ? (2 * pad + NN + 1) / 2 : 2 * pad + NN) + (Q + 1) / 2;
     w = (w + 3) & ~3;  // 16-byte multiple: the staging block and the ring are accessed with 128-bit LDS operations
@@ -2298,6 +2368,7 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->ws = (uint32_t*)((char*)ws + beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES);
     a->qtab_stride = qtab_stride_for(p);
     a->qtab = a->qtab_stride ? (uint16_t*)(a->ws + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * a->rec_words) : nullptr;  // behind the chain records
+    a->perm = perm_slots_for(p) ? (uint32_t*)((char*)a->qtab + qtab_bytes_for(p)) : nullptr;                                   // ... and behind that (qtab rows are 64-byte multiples)
     a->seeds = seeds, a->out = *out;
 #if defined(MCQ_STAMPS) || defined(MCQ_WAVE_TIMES)
     a->dbg = g_dbg;
@@ -2332,11 +2403,13 @@ int effective_lanes(const mcq_params* p) {
         if (p->mode == MCQ_MODE_FULL3D && p->N > 8 && p->N <= 12 && p->rng == MCQ_RNG_MT19937_NUMPY && p->exchange_every == 0) G = 4;
         // replica exchange: a ladder lives in one wavefront (its chains swap through cross-lane moves, no barrier)
         if (p->exchange_every > 0 && 64 / G < p->exchange_replicas) G = 64 / p->exchange_replicas;
+        if (p->mode == MCQ_MODE_FULL3D && p->N > 32) G = 16;  // 64-bit column words: four chains per wavefront (N = 64: 33 KB each)
     }
     return G;
 }
 
-template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false, bool CNT = false>
+template <int MODE, int G, bool PATIENCE, int NT, bool REDUCED, bool PHILOX = false, int NC = 0, bool EXCH = false, bool CAND5 = false, bool EARLYU = false, bool SLIM = false, bool CNT = false,
+          bool WIDE = false>
 int launch_sweep(const KArgs& a0, hipStream_t s) {
     constexpr int CPB = 64 / G;  // one wavefront per workgroup: chains never interact, so no barrier exists
     KArgs a = a0;
@@ -2349,9 +2422,9 @@ int launch_sweep(const KArgs& a0, hipStream_t s) {
         return fail(MCQ_EINVAL, MODE == MCQ_MODE_FULL3D && a.Q != a.NN ? "chain state does not fit in LDS (n_queens: the queen table of %s chains per wavefront exceeds 160 KB; more lanes_per_chain halve it)"
                                                                         : "chain state does not fit in LDS (%s chains per wavefront)", G == 2 ? "32" : G == 4 ? "16" : G == 8 ? "8" : "4");
     if (a.dry) return MCQ_OK;
-    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM, CNT, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((a.n_chains + CPB - 1) / CPB);
-    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM, CNT>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mcq_sweep_kernel<MODE, G, PATIENCE, NT, REDUCED, PHILOX, NC, EXCH, CAND5, EARLYU, SLIM, CNT, WIDE>), dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return MCQ_OK;
 }
@@ -2404,6 +2477,16 @@ int launch_sweep_g(const KArgs& a, hipStream_t s) {
     if (a.exch_every > 0) return launch_sweep_exchange<MODE, G>(a, s);
     if (a.rng == MCQ_RNG_PHILOX4X32_10) return launch_sweep_philox<MODE, G>(a, s);
     if constexpr (MODE == MCQ_MODE_FULL3D) {  // no early stop (experiments.py:199-279)
+        if (a.N > 32) {  // 64-bit column words (validate(): 16 lanes per chain, NumPy's stream, no exchange)
+            if constexpr (G == 16) {
+                KArgs b = a;
+                b.chain_lds_words = chain_lds_words_for(a.N, MCQ_MODE_FULL3D, false, a.Q, false, false, true);
+                return a.red ? launch_sweep<MODE, G, false, 0, true, false, 0, false, false, false, false, false, true>(b, s)
+                             : launch_sweep<MODE, G, false, 0, false, false, 0, false, false, false, false, false, true>(b, s);
+            } else {
+                return fail(MCQ_EINVAL, "full_3d beyond N = 32 runs at 16 lanes per chain");
+            }
+        }
         if constexpr (G == 8) {  // N <= 16: 16-bit column words, four lanes around each of the two cells
             const int nt = (a.N + 3) / 4;
             if (a.red && nt == 3) {  // BASELINE config 3's shape with the reduced trace
@@ -2631,18 +2714,16 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
     {
         const size_t D = 2 * (size_t)p->N - 1, lines = ((D * D + 3) / 4) * 4;
-        bool any_random = p->init == MCQ_INIT_RANDOM;
-        for (size_t t = 0; t < n_sets_of(p) && p->n_sets > 1; t++) any_random |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
-        const size_t perm = p->mode == MCQ_MODE_FULL3D && any_random ? (size_t)p->N * p->N * p->N * 2 : 0;
+        const size_t perm = p->mode == MCQ_MODE_FULL3D && any_random_init(p) && !a.perm ? (size_t)p->N * p->N * p->N * 2 : 0;  // (beyond N = 32: in global memory)
         init_lds += perm > lines ? perm : lines;
         init_lds = (init_lds + 15) & ~(size_t)15;
     }
     if (init_lds > 160 * 1024) return fail(MCQ_EINVAL, "initial state does not fit in LDS (N^3 permutation array + 3 Q state bytes)");
     const int init_ci = 4 * init_lds * 8 <= 160 * 1024 ? 4 : 2 * init_lds * 8 <= 160 * 1024 ? 2 : 1;
     a.init_words = (int)(init_lds / 4);
-    auto launch_init = [&](const KArgs& k) -> hipError_t {
+    auto launch_init_part = [&](const KArgs& k, long long count) -> hipError_t {  // chains k.chain0 .. k.chain0 + count - 1
         const size_t bytes = (size_t)init_ci * init_lds;
-        const unsigned grid = (unsigned)((k.n_chains + init_ci - 1) / init_ci);
+        const unsigned grid = (unsigned)((count + init_ci - 1) / init_ci);
         hipError_t e;
         if (init_ci == 4) {
             e = hipFuncSetAttribute((const void*)mcq_init_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -2655,6 +2736,16 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
             if (e == hipSuccess) hipLaunchKernelGGL(mcq_init_kernel<1>, dim3(grid), dim3(64), bytes, s, k);
         }
         return e;
+    };
+    auto launch_init = [&](const KArgs& k0) -> hipError_t {
+        if (!k0.perm) return launch_init_part(k0, k0.n_chains);
+        const long long slots = perm_slots_for(p);  // the permutation slices are shared: one launch after the other on the stream
+        KArgs k = k0;
+        for (k.chain0 = 0; k.chain0 < k0.n_chains; k.chain0 += slots) {
+            const hipError_t e = launch_init_part(k, k0.n_chains - k.chain0 < slots ? k0.n_chains - k.chain0 : slots);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     };
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     if (p->n_steps > 0) {
@@ -2687,7 +2778,7 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
                         }
                 b.seeds = a.seeds + t * (size_t)p->chains_per_set;
                 b.ws = a.ws + t * (size_t)p->chains_per_set * a.rec_words;
-                if (a.qtab) b.qtab = a.qtab + t * (size_t)p->chains_per_set * a.qtab_stride;
+                if (a.qtab) b.qtab = a.qtab + t * (size_t)p->chains_per_set * a.qtab_stride * (p->N > 32 ? 2 : 1);
                 b.n_chains = p->chains_per_set;
                 HIP_TRY(launch_init(b));
             }
@@ -2728,7 +2819,7 @@ int32_t mcq_default_lanes(int32_t mode) { return mode == MCQ_MODE_BOARD ? 4 : 8;
 
 // board: 4 lanes up to N = 12, where 16 chains per wavefront still fit 16 wavefronts per CU (<= 640 B of LDS per chain), and 8
 // beyond (65 536 chains x 20 000 steps: N = 13 42 ms against 49 ms, N = 16 42 / 52, N = 20 56 / 70, N = 24 56 / 73); full_3d: 8
-int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_BOARD && N > 12 ? 8 : mcq_default_lanes(mode); }
+int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_BOARD && N > 12 ? 8 : mode == MCQ_MODE_FULL3D && N > 32 ? 16 : mcq_default_lanes(mode); }
 
 int32_t mcq_effective_lanes(const mcq_params* p) { return validate(p) == MCQ_OK ? effective_lanes(p) : 0; }
 
@@ -2744,7 +2835,7 @@ size_t mcq_state_bytes_for(const mcq_params* p) { return validate(p) == MCQ_OK ?
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
     const size_t chains = (size_t)(p->n_chains > 0 ? p->n_chains : 1);
-    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + chains * rec_words_for(p) * 4 + chains * (size_t)qtab_stride_for(p) * 2;
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + chains * rec_words_for(p) * 4 + qtab_bytes_for(p) + perm_bytes_for(p);
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,

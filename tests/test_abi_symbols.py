@@ -63,6 +63,30 @@ def test_pure_helpers_without_gpu():
     assert b"N out of range" in L.mcq_last_error()
 
 
+def test_full_3d_beyond_32_sizing_and_limits():
+    """full_3d at N = 33..64 (64-bit column words): the workspace holds the queen table as 32-bit entries and, for a random init, the
+    N^3 cells np.random.choice permutes for at most 256 chains at a time; what the variant does not run is an explicit error."""
+    L = mcq_amd._lib.lib()
+    sp = {"type": "constant", "beta_const": 1.0}
+    make = mcq_amd.abi.make_params
+    fixed = 8192 + 4096 + 2048 * 16 * 4 + 128  # tables of 1000 steps, pacing rows, exchange ladder
+    rec = lambda Q: ((628 + (3 * Q + 3) // 4 + 15) & ~15) * 4  # noqa: E731  (chain record: MT words, cursor, E0, 3 Q state bytes; 64-byte multiple)
+    for chains, slots in ((10, 12), (1000, 256)):
+        p = make(64, 1000, "random", sp, chains, mcmc_type="full_3d")
+        assert L.mcq_workspace_bytes(ctypes.byref(p)) == fixed + chains * (rec(4096) + 4096 * 4) + slots * 64**3 * 4
+        p = make(64, 1000, "latin", sp, chains, mcmc_type="full_3d")
+        assert L.mcq_workspace_bytes(ctypes.byref(p)) == fixed + chains * (rec(4096) + 4096 * 4)
+    p = make(32, 1000, "random", sp, 10, mcmc_type="full_3d")  # up to N = 32: 16-bit entries, the permutation in LDS
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == fixed + 10 * (rec(1024) + 1024 * 2)
+    for kw, msg in (({"lanes_per_chain": 8}, b"16 lanes per chain"), ({"rng": "philox"}, b"MT19937 stream only")):
+        p = make(33, 1000, "random", sp, 16, mcmc_type="full_3d", **kw)
+        assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and msg in L.mcq_last_error()
+    p = make(48, 1000, "random", sp, 16, mcmc_type="full_3d")
+    mcq_amd.abi.set_exchange(p, 10, [1.0, 0.8, 0.6, 0.4])
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and b"without replica exchange" in L.mcq_last_error()
+    assert L.mcq_default_lanes_n(1, 40) == 16 and L.mcq_default_lanes_n(1, 32) == 8
+
+
 def test_n_chains_bound_and_diag_gate():
     """n_chains >= 2^31 is MCQ_EINVAL (one workgroup per chain in the init kernel); MCQ_DIAG_LIB alone does not swap the library."""
     import subprocess

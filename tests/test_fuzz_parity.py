@@ -232,3 +232,43 @@ def test_random_round4_feature_combinations():
             got, _ = mcq_amd._lib.run_host(p, seeds, trace=k["trace"])
             util.assert_results_equal(got, want, what, trace=bool(k["trace"]))
         assert got["near_ties"].sum() == 0, what
+
+
+def _wide_cases(n=int(os.environ.get("MCQ_FUZZ_WIDE_CASES", "40"))):
+    rng = np.random.default_rng(FUZZ_SEED + 5)
+    scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
+    out = []
+    for c in range(n):
+        st = str(rng.choice(scheds))
+        sp = {"type": st, "beta_const": float(rng.choice([0.0, 0.3, 1.0, 2.5]))} if st == "constant" else \
+            {"type": st, "beta_start": float(rng.choice([0.1, 0.5, 1.0])), "beta_end": float(rng.choice([2.0, 3.0, 6.0]))}
+        N = int(rng.choice([33, 34, 40, 41, 47, 48, 56, 63, 64]))
+        k = dict(c=c, N=N, sp=sp, n_steps=int(rng.choice([0, 1, 16, 17, 100, 300, 700])) if not FUZZ_LONG else int(rng.choice([1500, 4000])),
+                 init=str(rng.choice(["random", "latin", "klarner"])), n_chains=int(rng.choice([1, 3, 4, 5, 9])), Q=None,
+                 trace=[True, False, "reduced"][int(rng.integers(0, 3))], lanes=int(rng.choice([0, 16])), seed0=int(rng.integers(0, 2**31)))
+        if rng.random() < 0.3:
+            k.update(Q=int(rng.integers(2, 32768)), init="random")
+        out.append(k)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_random_full_3d_beyond_32():
+    """full_3d at N = 33..64 (64-bit column words; queens and the init kernel's permutation in global memory) at random: every init, schedule
+    and trace mode, queen counts up to 32 767, chain counts around a wavefront's four."""
+    for k in _wide_cases():
+        what = str(k)
+        p = abi.make_params(k["N"], k["n_steps"], k["init"], k["sp"], k["n_chains"], mcmc_type="full_3d", lanes_per_chain=k["lanes"], Q=k["Q"], trace=k["trace"])
+        seeds = abi.seeds_for(k["seed0"], k["n_chains"])
+        want = oracle.run(p, seeds, n_threads=8, fast=bool(k["c"] & 1))
+        if k["trace"] == "reduced":
+            got, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced")
+            util.assert_results_equal(got, want, what, trace=False)
+            st = mcq_amd.jobs.stats_from_trace(want, k["n_steps"])
+            for f in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+                np.testing.assert_array_equal(got[f], st[f], err_msg=f"{what}: {f}")
+        else:
+            got, _ = mcq_amd._lib.run_host(p, seeds, trace=k["trace"])
+            util.assert_results_equal(got, want, what, trace=bool(k["trace"]))
+        assert got["near_ties"].sum() == 0, what

@@ -64,6 +64,46 @@ def test_golden_boards_beyond_32(golden):
         mcq_amd._lib.run_host(abi.make_params(128, 10, "random", sp, 4, mcmc_type="board", lanes_per_chain=4), abi.seeds_for(1, 4))
 
 
+def test_golden_full_3d_beyond_32(golden):
+    """full_3d up to N = 64 (64-bit column words, 16 lanes per chain, the queens and the init kernel's N^3 permutation in global memory): the
+    reference's chains at N = 33..64 (mcmc.py:6-18 is unbounded), then against the oracle: more chains than the init kernel has permutation
+    slices (its launches come one after the other), the reduced trace, sets with different inits, Q != N^2."""
+    for case in golden.chains_wide:
+        for lanes in (0, 16):
+            p = util.params_for_case(case, lanes_per_chain=lanes)
+            res, _ = mcq_amd._lib.run_host(p, np.array([case["seed"]], dtype=np.uint32))
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"hip G={lanes} vs reference {case}")
+    sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}
+    for N, init, n, n_steps, Q in ((33, "random", 301, 400, None), (64, "random", 6, 1500, None), (47, "klarner", 9, 1500, None), (64, "latin", 5, 3000, None),
+                                   (50, "random", 7, 1500, 700), (36, "random", 10, 1500, 20000)):
+        p = abi.make_params(N, n_steps, init, sp, n, mcmc_type="full_3d", Q=Q)
+        seeds = abi.seeds_for(500 + N, n)
+        want = oracle.run(p, seeds, fast=True, n_threads=8)
+        got, _ = mcq_amd._lib.run_host(p, seeds)
+        util.assert_results_equal(got, want, f"N={N} {init} Q={Q}")
+        assert got["near_ties"].sum() == 0
+    # reduced trace
+    p = abi.make_params(40, 2000, "random", sp, 21, mcmc_type="full_3d")
+    seeds = abi.seeds_for(9, 21)
+    want = oracle.run(p, seeds, fast=True, n_threads=8)
+    got, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced")
+    util.assert_results_equal(got, want, "N=40 reduced", trace=False)
+    st = mcq_amd.jobs.stats_from_trace(want, 2000)
+    for k in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+        np.testing.assert_array_equal(got[k], st[k], err_msg=k)
+    # three schedule sets, each with its own init (the init kernel runs once per set, on its part of the queen table)
+    scheds = [sp, {"type": "constant", "beta_const": 2.0}, {"type": "sinusoidal_annealing", "beta_start": 0.1, "beta_end": 5.0}]
+    p = abi.make_params_sets(35, 800, "random", scheds, 16, mcmc_type="full_3d", init_modes=["klarner", "random", "latin"])
+    seeds = np.concatenate([abi.seeds_for(70 + 1000 * t, 16) for t in range(3)])
+    want = oracle.run(p, seeds, fast=True, n_threads=8)
+    got, _ = mcq_amd._lib.run_host(p, seeds)
+    util.assert_results_equal(got, want, "N=35 three sets")
+    # what stays an explicit error
+    for kw, msg in (({"lanes_per_chain": 8}, "16 lanes per chain"), ({"rng": "philox"}, "MT19937 stream only")):
+        with pytest.raises(ValueError, match=msg):
+            mcq_amd._lib.run_host(abi.make_params(33, 10, "random", sp, 4, mcmc_type="full_3d", **kw), abi.seeds_for(1, 4))
+
+
 def test_queen_counts_against_the_oracle():
     """Q != N^2 at sizes the golden chains do not reach: many chains per launch, reduced trace, Philox, sets."""
     sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}

@@ -46,9 +46,21 @@ def test_golden_boards_beyond_32(golden):
             util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
     sp = {"type": "constant", "beta_const": 1.0}
     abi.make_params(128, 10, "random", sp, 1, mcmc_type="board")
-    for N, mode in ((129, "board"), (33, "full_3d")):
+    for N, mode in ((129, "board"), (65, "full_3d")):
         with pytest.raises(ValueError, match="N must be in"):
             abi.make_params(N, 10, "random", sp, 1, mcmc_type=mode)
+
+
+def test_golden_full_3d_beyond_32(golden):
+    """State3DQueens is unbounded (mcmc.py:6-18); this build runs full_3d up to N = 64: 17 reference chains at N = 33..64 (random --
+    np.random.choice over up to 262 144 cells --, latin, klarner with its fallback core, one with Q != N^2), the naive scan and the
+    line-counter variant."""
+    assert len(golden.chains_wide) >= 17
+    for case in golden.chains_wide:
+        p = util.params_for_case(case)
+        for fast in (False, True):
+            res = oracle.run(p, np.array([case["seed"]], dtype=np.uint32), fast=fast)
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
 
 
 def test_queen_count_errors():

@@ -37,8 +37,14 @@ class Golden:
         """board chains beyond N = 32 (the reference is unbounded, mcmc_board.py:12)"""
         return self.manifest["chains_big"]
 
+    @property
+    def chains_wide(self):
+        """full_3d chains beyond N = 32 (the reference is unbounded, mcmc.py:6-18)"""
+        return self.manifest["chains_wide"]
+
     def chain(self, case):
-        z = self.npz("chains_q" if case["key"].startswith("q") else "chains_big" if case["key"].startswith("big") else "chains")
+        key = case["key"]
+        z = self.npz("chains_q" if key.startswith("q") else "chains_big" if key.startswith("big") else "chains_wide" if key.startswith("wide") else "chains")
         return {k: z[f"{case['key']}_{k}"] for k in
                 ("hist", "accept", "n_executed", "best_energy", "final_energy", "steps_to_best", "best_state", "final_state")}
 

@@ -210,6 +210,20 @@ def big_cases():
     return cases
 
 
+def wide_cases():
+    """full_3d chains beyond N = 32 (State3DQueens is unbounded, mcmc.py:6-18; this build runs full_3d up to N = 64 with 64-bit
+    column words): chains_wide.npz / manifest["chains_wide"], `python tools/gen_golden.py --only wide`."""
+    cases = []
+    for N, init, n_steps in ((33, "random", 300), (33, "klarner", 200), (33, "latin", 200), (41, "random", 200), (48, "random", 200), (48, "klarner", 150),
+                             (64, "random", 120), (64, "latin", 120)):
+        for seed in (42, 1042):
+            cases.append({"mode": "full_3d", "init": init, "schedule": SCHEDULES[1], "N": N, "seed": seed, "n_steps": n_steps})
+    cases.append({"mode": "full_3d", "init": "random", "schedule": SCHEDULES[0], "N": 40, "Q": 3000, "seed": 7, "n_steps": 300})
+    for idx, c in enumerate(cases):
+        c["key"] = f"wide{idx:03d}"
+    return cases
+
+
 def gen_beta(ref_path, out):
     """F5: float64 beta(step) tables of the five schedule closures."""
     ex = _ref(ref_path)
@@ -306,12 +320,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--workers", type=int, default=8)
-    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz); 'big': only the boards beyond N = 32 (chains_big.npz); merged into the existing manifest")
+    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz); 'big': only the boards beyond N = 32 (chains_big.npz); 'wide': only the full_3d chains beyond N = 32 (chains_wide.npz); merged into the existing manifest")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    if args.only in ("q", "big"):
+    if args.only in ("q", "big", "wide"):
         name = "chains_" + args.only
-        cases = q_cases() if args.only == "q" else big_cases()
+        cases = {"q": q_cases, "big": big_cases, "wide": wide_cases}[args.only]()
         with ProcessPoolExecutor(max_workers=args.workers) as pool:
             results = list(pool.map(run_chain, [(args.reference, c) for c in cases], chunksize=2))
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **{f"{c['key']}_{k}": v for c, r in zip(cases, results) for k, v in r.items()})
