@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCQ_ABI_VERSION 4
+#define MCQ_ABI_VERSION 5
 
 /* error codes */
 #define MCQ_OK 0
@@ -158,6 +158,13 @@ typedef struct mcq_params {
                                       device with a hipMemcpyAsync on the caller's stream from THIS (normally pageable) array, so it must stay valid until
                                       that copy has run -- mcq_run_host and the Python wrappers keep it alive and synchronise; a caller of mcq_run_device
                                       keeps it until the stream has passed the call (with exchange the call cannot be part of a stream capture) */
+    /* Chains that CONTINUE a random stream instead of seeding one: metropolis_mcmc[_board](..., seed=None) skips np.random.seed and draws from
+     * NumPy's global RandomState wherever it stands (experiments.py:200-201, 287-288).  Optional, uint32[n_chains][625]: per chain the 624 key
+     * words and the position (0..624) of an MT19937 state exactly as np.random.get_state() returns them; seeds[r] is ignored for such a run.
+     * HOST pointer (also for mcq_run_device: the library rewinds the unconsumed part of the generation into the layout its kernels stream from,
+     * copies the states to the workspace and synchronises the stream once); MCQ_RNG_MT19937_NUMPY only.  mcq_outputs.stream_words tells how far
+     * each chain went, so the caller can advance its own copy of the stream by as many words. */
+    const uint32_t* stream_states;
 } mcq_params;
 
 /*
@@ -189,6 +196,10 @@ typedef struct mcq_outputs {
     /* exchange_every > 0 only, optional [n_chains] each: */
     int32_t* exchange_rung;  /* the rung the chain ends on */
     int64_t* n_exchanges;    /* accepted swaps the chain took part in */
+    uint32_t* stream_words;  /* optional [n_chains]: 32-bit words the chain took from its random stream -- initial state, every step's draws (the
+                                rejected words of randint included), exchange uniforms -- modulo 2^32; 0 with MCQ_RNG_PHILOX4X32_10 (a stream addressed
+                                by position: nothing to hand back).  Equal between the oracle and the kernels like every other output: the streams
+                                are consumed identically, not only the results */
 } mcq_outputs;
 
 /* ---- exported by libmcq_hip.so ------------------------------------------------------------ */
@@ -201,6 +212,10 @@ int mcq_device_count(void);
  * N = 32, the only width of that variant; 4 for N = 9..12 with NumPy's stream) (mcq_default_lanes: the value for small boards).  A board launch that leaves SIMDs empty runs at twice or four times the
  * lanes while every wavefront still has a SIMD to itself (N >= 20: at most 8; N <= 8: always 4); with replica exchange a ladder must fit one
  * wavefront.  mcq_effective_lanes tells.  The lane count never changes a result. */
+/* mcq_params.stream_states, one chain: an MT19937 state as np.random.get_state() holds it (uint32[625]: key, position) in the layout the kernels stream
+ * from (uint32[626]: words [0, out[625]) of the current generation, the rest rewound to the generation before; out[624] = position).  Pure host code:
+ * what mcq_run_device does with every state before it copies them to the workspace; exported for the tests. */
+void mcq_stream_layout(const uint32_t* numpy_state, uint32_t* out);
 int32_t mcq_default_lanes(int32_t mode);
 int32_t mcq_default_lanes_n(int32_t mode, int32_t N);
 /* the lane count a launch with these parameters really runs with (lanes_per_chain, or the default above and its small-launch

@@ -133,6 +133,8 @@ def lib():
         L.mcq_device_count.restype = C.c_int
         L.mcq_default_lanes.restype = C.c_int32
         L.mcq_default_lanes.argtypes = [C.c_int32]
+        L.mcq_stream_layout.restype = None
+        L.mcq_stream_layout.argtypes = [C.c_void_p, C.c_void_p]
         L.mcq_default_lanes_n.restype = C.c_int32
         L.mcq_default_lanes_n.argtypes = [C.c_int32, C.c_int32]
         L.mcq_effective_lanes.restype = C.c_int32
@@ -238,7 +240,7 @@ class DeviceRun:
         self.p = abi.copy_params(params)
         self.p.trace = abi.trace_mode(trace)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        tdt = {np.int32: torch.int32, np.int64: torch.int64, np.uint8: torch.uint8, np.uint64: torch.int64}
+        tdt = {np.int32: torch.int32, np.int64: torch.int64, np.uint8: torch.uint8, np.uint64: torch.int64, np.uint32: torch.int32}
         self.t = {}
         self.out = abi.Outputs()
         with torch.cuda.device(self.device):
@@ -306,5 +308,5 @@ class DeviceRun:
         res = {}
         for k, t in self.t.items():
             a = t.cpu().numpy()
-            res[k] = a.view(np.uint64) if abi.OUTPUT_DTYPES[k] is np.uint64 else a
+            res[k] = a.view(np.uint64) if abi.OUTPUT_DTYPES[k] is np.uint64 else a.view(np.uint32) if abi.OUTPUT_DTYPES[k] is np.uint32 else a
         return res

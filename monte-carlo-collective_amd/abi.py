@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, EINVAL, EDEVICE, ENOMEM = 0, -1, -2, -3
 
@@ -79,6 +79,7 @@ class Params(C.Structure):
         ("exchange_replicas", C.c_int32),
         ("n_queens", C.c_int32),
         ("exchange_ladder", C.POINTER(C.c_double)),
+        ("stream_states", C.c_void_p),
     ]
 
 
@@ -107,6 +108,7 @@ class Outputs(C.Structure):
         ("step_count", C.c_void_p),
         ("exchange_rung", C.c_void_p),
         ("n_exchanges", C.c_void_p),
+        ("stream_words", C.c_void_p),
     ]
 
 
@@ -130,6 +132,7 @@ OUTPUT_DTYPES = {
     "step_count": np.int64,
     "exchange_rung": np.int32,
     "n_exchanges": np.int64,
+    "stream_words": np.uint32,
 }
 
 
@@ -152,7 +155,7 @@ def output_shapes(p, trace=True, states=True):
     """name -> shape for the arrays a call with parameters `p` fills."""
     n = p.n_chains
     shapes = {k: (n,) for k in ("hist_len", "steps_executed", "initial_energy", "best_energy", "final_energy",
-                                "steps_to_best", "n_accepted", "near_ties")}
+                                "steps_to_best", "n_accepted", "near_ties", "stream_words")}
     if isinstance(trace, str) and trace == "reduced":
         for k in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
             shapes[k] = (p.n_sets, p.n_steps + 1) if p.n_sets > 1 else (p.n_steps + 1,)
@@ -348,7 +351,7 @@ def copy_params(params):
     keep = getattr(params, "_sets_keepalive", None)
     if keep is not None:
         p._sets_keepalive = keep
-    for k in ("_schedules", "_beta_keepalive", "_ladder_keepalive"):
+    for k in ("_schedules", "_beta_keepalive", "_ladder_keepalive", "_stream_keepalive"):
         if hasattr(params, k):
             setattr(p, k, getattr(params, k))
     return p
@@ -370,6 +373,30 @@ def host_beta_table(params):
 
     sch = [as_dict(params.sets[t]) for t in range(int(params.n_sets))] if params.n_sets > 1 else [as_dict(params)]
     return np.ascontiguousarray(np.stack([beta_values(sp, params.n_steps) for sp in sch]))
+
+
+def set_stream_states(params, states):
+    """Chains that continue MT19937 streams instead of seeding them (include/mcq.h: stream_states; metropolis_mcmc(seed=None),
+    experiments.py:200-201, 287-288): `states` is one np.random.get_state() tuple -- ('MT19937', key[624], pos, ...) -- per chain, or an
+    array [n_chains][625] of key words + position.  Returns params."""
+    if isinstance(states, np.ndarray):
+        arr = np.ascontiguousarray(states, dtype=np.uint32)
+    else:
+        if isinstance(states, tuple) and len(states) >= 3 and isinstance(states[0], str):
+            states = [states]
+        rows = []
+        for st in states:
+            if st[0] != "MT19937":
+                raise ValueError("only MT19937 states can be continued")
+            rows.append(np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([int(st[2])], dtype=np.uint32)]))
+        arr = np.ascontiguousarray(np.stack(rows))
+    if arr.shape != (params.n_chains, 625):
+        raise ValueError("one MT19937 state (624 key words + position) per chain")
+    if (arr[:, 624] > 624).any():
+        raise ValueError("MT19937 position out of range")
+    params.stream_states = arr.ctypes.data
+    params._stream_keepalive = arr
+    return params
 
 
 def set_exchange(params, every, ladder):

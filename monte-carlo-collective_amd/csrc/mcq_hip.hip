@@ -61,6 +61,7 @@
 #include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/mcq.h"
 
@@ -158,6 +159,7 @@ struct KArgs {
     int qtab_stride;          // keep their queen table out of LDS work on it, the init kernel fills it).  Beyond N = 32: uint32 entries i | j << 8 | k << 16
     uint32_t* perm;           // full_3d beyond N = 32, random init: the N^3 cells np.random.choice permutes, one slice per chain of an init launch (workspace)
     long long chain0;         // init kernel: first chain of this launch (the launches of one run share the `perm` slices)
+    const uint32_t* stream;   // mcq_params.stream_states in the layout the kernels stream from, [n_chains][626]: MT words, position, words of the current generation (workspace)
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -208,6 +210,7 @@ struct InitRng {
     uint32_t* mt;
     uint32_t win;
     int pos, gen_end, sub, gbase, L;  // sub: lane inside the chain's group; gbase: first lane of the group
+    int wraps;                        // generations finished (mcq_outputs.stream_words)
     bool philox;
     uint32_t key;
 
@@ -237,7 +240,7 @@ struct InitRng {
         if (off == 0) fill(pos);
         const uint32_t w = (uint32_t)__shfl((int)win, gbase + off, 64);
         pos++;
-        if (!philox && pos == MT_N) pos = 0, gen_end = 0;
+        if (!philox && pos == MT_N) pos = 0, gen_end = 0, wraps++;
         return w;
     }
     // RandomState.randint(0, m + 1) / shuffle's random_interval: masked rejection on 32-bit words;
@@ -385,16 +388,25 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
         return v;
     };
 
-    {  // init_genrand: key[p] = s; s = 1812433253 * (s ^ (s >> 30)) + p + 1
+    InitRng rng;
+    rng.mt = mt, rng.win = 0, rng.pos = 0, rng.gen_end = 0, rng.sub = sub, rng.gbase = lane - sub, rng.L = L;  // NumPy's pos == 624: the first draw starts a generation
+    rng.philox = a.rng == MCQ_RNG_PHILOX4X32_10, rng.key = a.seeds[chain], rng.wraps = 0;
+    if (a.stream) {
+        // the chain continues a caller's stream (mcq_params.stream_states; seed=None in the reference): words [0, gen_end) of the record belong to the
+        // current generation, the rest to the one before (stream_layout() on the host rewound them), gen_end a multiple of 64 or 624
+        const uint32_t* g = a.stream + chain * 626LL;
+        for (int p = sub; p < MT_N; p += L) mt[p] = g[p];
+        rng.pos = (int)g[624], rng.gen_end = (int)g[625];
+        __syncthreads();  // (a workgroup of one wavefront: orders the LDS writes before the window's reads for the compiler as well)
+        if (rng.pos & (L - 1)) rng.fill(rng.pos & ~(L - 1));  // the window next() refills at every L-th word
+    } else {  // init_genrand: key[p] = s; s = 1812433253 * (s ^ (s >> 30)) + p + 1
         uint32_t s = a.seeds[chain];
         for (int p = 0; p < MT_N; p++) {
             if (sub == (p & (L - 1))) mt[p] = s;
             s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)p + 1u;
         }
     }
-    InitRng rng;
-    rng.mt = mt, rng.win = 0, rng.pos = 0, rng.gen_end = 0, rng.sub = sub, rng.gbase = lane - sub, rng.L = L;  // NumPy's pos == 624: the first draw starts a generation
-    rng.philox = a.rng == MCQ_RNG_PHILOX4X32_10, rng.key = a.seeds[chain];
+    const int pos_start = rng.pos;
 
     const unsigned mN = (unsigned)(N - 1);
     if (a.mode == MCQ_MODE_BOARD) {
@@ -541,6 +553,7 @@ __global__ __launch_bounds__(64) void mcq_init_kernel(KArgs a) {
     uint32_t* rec = a.ws + chain * (long long)a.rec_words;
     for (int w = sub; w < MT_N; w += L) rec[w] = mt[w];
     if (sub == 0) rec[REC_MIRROR] = mt[0], rec[REC_POS] = (uint32_t)rng.pos, rec[REC_GEN_END] = (uint32_t)rng.gen_end, rec[REC_E0] = (uint32_t)e;
+    if (sub == 0 && a.out.stream_words) a.out.stream_words[chain] = rng.philox ? 0u : (uint32_t)(rng.wraps * MT_N + rng.pos - pos_start);  // the sweep adds its own
     uint8_t* rst = (uint8_t*)(rec + REC_STATE);
     for (int c = sub; c < a.state_bytes; c += L) rst[c] = st[c];
     if (a.mode == MCQ_MODE_FULL3D && a.qtab) {
@@ -2051,6 +2064,11 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             if (a.out.steps_to_best) a.out.steps_to_best[chain] = cold[C_BEST_STEP];
             if (a.out.n_accepted) a.out.n_accepted[chain] = cold[C_N_ACC];
             if (a.out.near_ties) a.out.near_ties[chain] = cold[C_TIES];
+            // mcq_outputs.stream_words: where the chain's stream stands, left in the record's gen_end word (read once, when the stream was attached); the init
+            // kernel wrote the words IT took and mcq_stream_words_kernel adds this position minus the one the sweep started from.  (Through the stream's own
+            // base + offset registers: a store to a.out.stream_words here would keep three more kernel arguments alive across the loop -- 2 VGPRs and 3-17
+            // spilled SGPRs more in every variant.)
+            if constexpr (!PHILOX) *rng.word(REC_GEN_END) = rng.pos;  // (a Philox stream is addressed by position, there is nothing to hand back: stream_words is 0)
             if (EXCH && a.out.exchange_rung) a.out.exchange_rung[chain] = rung;
             if (EXCH && a.out.n_exchanges) a.out.n_exchanges[chain] = n_exch;
         }
@@ -2059,6 +2077,13 @@ __global__ __launch_bounds__(64, G == 2 ? MCQ_G2_WAVES : (MODE == MCQ_MODE_FULL3
             copy_state_out<MODE, G, PATIENCE || REDUCED>(fo, hts, qn, Q, gl);
         }
     }
+}
+
+// mcq_outputs.stream_words = the init kernel's count (already there) + the words the sweep took: final position (left in the record's gen_end word by
+// the sweep's epilogue) minus the position the init kernel handed over, modulo 2^32
+__global__ __launch_bounds__(256) void mcq_stream_words_kernel(uint32_t* __restrict__ words, const uint32_t* __restrict__ ws, int rec_words, long long n_chains) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r < n_chains) words[r] += ws[r * rec_words + REC_GEN_END] - ws[r * rec_words + REC_POS];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2256,6 +2281,11 @@ int validate(const mcq_params* p) {
         if ((int64_t)p->n_queens >= (int64_t)p->N * p->N * p->N) return fail(MCQ_EINVAL, "n_queens must leave a free cell: Q < N^3 (the reference raises for Q > N^3 and never returns for Q = N^3)");
         if (p->n_queens > 32767) return fail(MCQ_EINVAL, "n_queens above 32767 is not supported by this build");
     }
+    if (p->stream_states) {
+        if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "stream_states continues an MT19937 stream (a Philox stream is a function of its seed)");
+        for (int64_t r = 0; r < p->n_chains; r++)
+            if (p->stream_states[r * 625 + 624] > 624u) return fail(MCQ_EINVAL, "stream_states: MT19937 position out of range");
+    }
     if (p->exchange_every < 0) return fail(MCQ_EINVAL, "negative exchange_every");
     if (p->exchange_every > 0) {
         const int R = p->exchange_replicas;
@@ -2297,6 +2327,38 @@ long long perm_slots_for(const mcq_params* p) {
     return p->n_chains < PERM_SLOTS ? ((p->n_chains > 0 ? p->n_chains : 1) + 3) & ~3LL : PERM_SLOTS;  // (a multiple of the init kernel's chains per wavefront)
 }
 size_t perm_bytes_for(const mcq_params* p) { return (size_t)perm_slots_for(p) * (size_t)p->N * p->N * p->N * 4; }
+// mcq_params.stream_states in the kernels' layout: 626 words per chain (stream_layout), behind everything else in the workspace
+size_t stream_bytes_for(const mcq_params* p) { return p->stream_states ? (size_t)(p->n_chains > 0 ? p->n_chains : 1) * 626 * 4 : 0; }
+
+// An MT19937 state as NumPy holds it -- 624 key words of the CURRENT generation, `pos` of them consumed -- in the layout the kernels stream from:
+// words [0, ge) of the current generation, words [ge, 624) of the one BEFORE (the kernels twist a generation block by block, in place, as its words
+// are needed), ge = pos rounded up to a multiple of 64 (at most 63 ready words: what the sweep's ring takes over), out[624] = pos, out[625] = ge.
+// Rewinding word j of a generation: the twist made new[i] = x_i ^ (y_i >> 1) ^ (y_i odd ? A : 0) with y_i = (old[i] & UPPER) | (old[i+1] & LOWER) and
+// x_i = old[i + 397] (i < 227) or new[i - 227]; A has its top bit set and y_i >> 1 has not, so new[i] ^ x_i gives y_i back, and old[j] = (y_j & UPPER) |
+// (y_{j-1} & LOWER).  (old[0]'s low bits went into nothing -- y_623 took new[0]'s -- and nothing reads them: the key's own are kept.)
+void stream_layout(const uint32_t* st, uint32_t* out) {
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    const int pos = (int)st[624];
+    memcpy(out, st, 624 * sizeof(uint32_t));
+    if (pos >= 624) {  // nothing of the key's generation is left: it is the "one before" of the generation the next draw starts
+        out[624] = 0, out[625] = 0;
+        return;
+    }
+    const int ge = (pos + 63) & ~63;
+    out[624] = (uint32_t)pos, out[625] = (uint32_t)(ge > 624 ? 624 : ge);
+    if (ge >= 624) return;
+    uint32_t y_next = 0;  // y_{i+1} while walking down
+    for (int i = 623; i >= (ge > 0 ? ge - 1 : 0); i--) {
+        const uint32_t x = i < 227 ? out[i + 397] : st[i - 227];  // (i < 227: old[i + 397], rewound earlier in this walk since i + 397 > i >= ge - 1)
+        uint32_t t = st[i] ^ x;
+        const uint32_t odd = t >> 31;
+        if (odd) t ^= A;
+        const uint32_t y = (t << 1) | odd;
+        if (i + 1 <= 623 && i + 1 >= ge) out[i + 1] = (y_next & UP) | (y & LO);  // old[i + 1] = upper bit from y_{i+1}, the rest from y_i
+        y_next = y;
+    }
+    if (ge == 0) out[0] = (y_next & UP) | (st[0] & LO);  // old[0]: only its upper bit is ever read
+}
 
 size_t n_sets_of(const mcq_params* p) { return p->n_sets > 1 ? (size_t)p->n_sets : 1; }
 // one table per schedule set, tab_stride elements apart (a 256-byte multiple for either element size)
@@ -2369,6 +2431,7 @@ int build_args(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* ou
     a->qtab_stride = qtab_stride_for(p);
     a->qtab = a->qtab_stride ? (uint16_t*)(a->ws + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * a->rec_words) : nullptr;  // behind the chain records
     a->perm = perm_slots_for(p) ? (uint32_t*)((char*)a->qtab + qtab_bytes_for(p)) : nullptr;                                   // ... and behind that (qtab rows are 64-byte multiples)
+    a->stream = p->stream_states ? (const uint32_t*)((char*)(a->ws + (size_t)(p->n_chains > 0 ? p->n_chains : 1) * a->rec_words) + qtab_bytes_for(p) + perm_bytes_for(p)) : nullptr;
     a->seeds = seeds, a->out = *out;
 #if defined(MCQ_STAMPS) || defined(MCQ_WAVE_TIMES)
     a->dbg = g_dbg;
@@ -2709,6 +2772,12 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
     }
     if (p->exchange_every > 0)  // 16 doubles at most, from the caller's (host) array
         HIP_TRY(hipMemcpyAsync((void*)a.exch_ladder, p->exchange_ladder, (size_t)p->exchange_replicas * 8, hipMemcpyHostToDevice, s));
+    if (a.stream) {  // the caller's MT19937 states in the kernels' layout; the staging array lives until the copy has run (hence the synchronisation)
+        std::vector<uint32_t> staged((size_t)p->n_chains * 626);
+        for (int64_t r = 0; r < p->n_chains; r++) stream_layout(p->stream_states + r * 625, staged.data() + r * 626);
+        HIP_TRY(hipMemcpyAsync((void*)a.stream, staged.data(), staged.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     // init kernel: LDS per chain = the MT19937 words, the state, and behind it the permutation array of np.random.choice (full_3d random
     // init), later one family of E0 line counters; four chains per wavefront while a CU still holds 8 wavefronts of them, else two or one (full_3d N = 12: 6.7 ms at two, 8.2 ms at four, 7.8 ms at one)
     size_t init_lds = (size_t)MT_N * 4 + ((a.state_bytes + 3) & ~3);
@@ -2779,6 +2848,8 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
                 b.seeds = a.seeds + t * (size_t)p->chains_per_set;
                 b.ws = a.ws + t * (size_t)p->chains_per_set * a.rec_words;
                 if (a.qtab) b.qtab = a.qtab + t * (size_t)p->chains_per_set * a.qtab_stride * (p->N > 32 ? 2 : 1);
+                if (a.stream) b.stream = a.stream + t * (size_t)p->chains_per_set * 626;
+                if (a.out.stream_words) b.out.stream_words = a.out.stream_words + t * (size_t)p->chains_per_set;
                 b.n_chains = p->chains_per_set;
                 HIP_TRY(launch_init(b));
             }
@@ -2789,6 +2860,10 @@ int run_device_impl(const mcq_params* p, const uint32_t* seeds, const mcq_output
 
     rc = p->mode == MCQ_MODE_BOARD ? launch_sweep_mode<MCQ_MODE_BOARD>(a, G, s) : launch_sweep_mode<MCQ_MODE_FULL3D>(a, G, s);
     if (rc != MCQ_OK) return rc;
+    if (out->stream_words && p->rng == MCQ_RNG_MT19937_NUMPY) {
+        hipLaunchKernelGGL(mcq_stream_words_kernel, dim3((unsigned)((p->n_chains + 255) / 256)), dim3(256), 0, s, out->stream_words, a.ws, a.rec_words, (long long)p->n_chains);
+        HIP_TRY(hipGetLastError());
+    }
     if (a.red) {
         const long long n_entries = p->n_steps + 1;
         for (size_t t = 0; t < n_sets_of(p); t++)
@@ -2823,6 +2898,8 @@ int32_t mcq_default_lanes_n(int32_t mode, int32_t N) { return mode == MCQ_MODE_B
 
 int32_t mcq_effective_lanes(const mcq_params* p) { return validate(p) == MCQ_OK ? effective_lanes(p) : 0; }
 
+void mcq_stream_layout(const uint32_t* numpy_state, uint32_t* out) { stream_layout(numpy_state, out); }
+
 int32_t mcq_device_simds(void) { return device_simds(); }
 
 size_t mcq_state_bytes(int32_t N, int32_t mode) {
@@ -2835,7 +2912,7 @@ size_t mcq_state_bytes_for(const mcq_params* p) { return validate(p) == MCQ_OK ?
 size_t mcq_workspace_bytes(const mcq_params* p) {
     if (validate(p) != MCQ_OK) return 0;
     const size_t chains = (size_t)(p->n_chains > 0 ? p->n_chains : 1);
-    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + chains * rec_words_for(p) * 4 + qtab_bytes_for(p) + perm_bytes_for(p);
+    return beta_tab_bytes(p) + c32_tab_bytes(p) + red_bytes(p) + PACE_BYTES + LADDER_BYTES + chains * rec_words_for(p) * 4 + qtab_bytes_for(p) + perm_bytes_for(p) + stream_bytes_for(p);
 }
 
 int mcq_run_device(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* out, void* workspace,
@@ -3025,6 +3102,7 @@ int mcq_run_host(const mcq_params* p, const uint32_t* seeds, const mcq_outputs* 
         {(void**)&d.steps_to_best, out->steps_to_best, n * 8},
         {(void**)&d.n_accepted, out->n_accepted, n * 8},
         {(void**)&d.near_ties, out->near_ties, n * 8},
+        {(void**)&d.stream_words, out->stream_words, n * 4},
         {(void**)&d.exchange_rung, p->exchange_every > 0 ? out->exchange_rung : nullptr, n * 4},
         {(void**)&d.n_exchanges, p->exchange_every > 0 ? out->n_exchanges : nullptr, n * 8},
         {(void**)&d.best_state, out->best_state, n * sb},

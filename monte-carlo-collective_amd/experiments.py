@@ -161,14 +161,17 @@ def _state(mode, N, row, energy):
 # the sweep
 # --------------------------------------------------------------------------------------------
 def run_chains(N, n_steps, init_mode, schedule_params, seeds, mcmc_type="full_3d", early_stop_patience=None,
-               trace=True, states=True, flags=0, lanes_per_chain=0, Q=None):
-    """Lowest Python level: every chain of `seeds` in one GPU launch.
+               trace=True, states=True, flags=0, lanes_per_chain=0, Q=None, stream_states=None):
+    """Lowest Python level: every chain of `seeds` in one GPU launch.  `stream_states` (one np.random.get_state() tuple or uint32[625] row per
+    chain): the chains continue those MT19937 streams instead of seeding their own; `stream_words` of the result says how far each went.
 
     Returns (result dict of NumPy arrays as described in include/mcq.h, kernel seconds)."""
     seeds = np.asarray(seeds)
     params = abi.make_params(N, n_steps, init_mode, schedule_params, len(seeds), mcmc_type=mcmc_type,
                              early_stop_patience=early_stop_patience, trace=trace, flags=flags,
                              lanes_per_chain=lanes_per_chain, Q=Q)
+    if stream_states is not None:
+        abi.set_stream_states(params, stream_states)
     if seeds.size and (seeds.min() < 0 or seeds.max() > 2**32 - 1):
         raise ValueError("Seed must be between 0 and 2**32 - 1")
     return _lib.run_host(params, seeds.astype(np.uint32), trace=trace, states=states)
@@ -207,14 +210,27 @@ def _params_of(beta_schedule, schedule_params):
     return p
 
 
+def _one_chain(seed, **kw):
+    """One chain, seeded (np.random.seed(seed), experiments.py:200-201, 287-288) or -- seed=None, the reference's default -- drawn from NumPy's
+    global stream where it stands: the chain runs on the device from a copy of np.random.get_state(), and the global stream is then moved past
+    the words the chain took (mcq_outputs.stream_words), so whatever draws from it next sees what it would see after the reference's call."""
+    if seed is not None:
+        return run_chains(seeds=[seed], **kw)[0]
+    st = np.random.get_state()
+    res, _ = run_chains(seeds=[0], stream_states=st, **kw)
+    left = int(res["stream_words"][0])
+    while left > 0:  # RandomState.randint over the full 32-bit range takes exactly one word per element
+        n = min(left, 1 << 24)
+        np.random.randint(0, 2**32, size=n, dtype=np.uint32)
+        left -= n
+    return res
+
+
 def metropolis_mcmc_board(N, n_steps, init_mode, beta_schedule, verbose=True, seed=None, run_idx=None,
                           early_stop_patience=None, schedule_params=None):
-    """experiments.py:282-376 for one chain.  `seed` is required: the reference's seed=None continues
-    the process-global NumPy stream, which has no meaning for a device-side stream."""
-    if seed is None:
-        raise ValueError("seed is required")
-    res, _ = run_chains(N, n_steps, init_mode, _params_of(beta_schedule, schedule_params), [seed], mcmc_type="board",
-                        early_stop_patience=early_stop_patience)
+    """experiments.py:282-376 for one chain; seed=None continues NumPy's global stream like the reference (_one_chain)."""
+    res = _one_chain(seed, N=N, n_steps=n_steps, init_mode=init_mode, schedule_params=_params_of(beta_schedule, schedule_params), mcmc_type="board",
+                     early_stop_patience=early_stop_patience)
     d = _chain_dict(res, 0, abi.MODE_BOARD, N)
     if verbose and n_steps > 0:
         print(d["final_energy"])
@@ -224,10 +240,8 @@ def metropolis_mcmc_board(N, n_steps, init_mode, beta_schedule, verbose=True, se
 
 def metropolis_mcmc(N, n_steps, init_mode, beta_schedule, verbose=True, seed=None, Q=None, run_idx=None,
                     early_stop_patience=None, schedule_params=None):
-    """experiments.py:199-279 for one chain; early_stop_patience is accepted and ignored, as there."""
-    if seed is None:
-        raise ValueError("seed is required")
-    res, _ = run_chains(N, n_steps, init_mode, _params_of(beta_schedule, schedule_params), [seed], mcmc_type="full_3d", Q=Q)
+    """experiments.py:199-279 for one chain; early_stop_patience is accepted and ignored, as there; seed=None continues NumPy's global stream."""
+    res = _one_chain(seed, N=N, n_steps=n_steps, init_mode=init_mode, schedule_params=_params_of(beta_schedule, schedule_params), mcmc_type="full_3d", Q=Q)
     d = _chain_dict(res, 0, abi.MODE_FULL3D, N)
     if verbose and n_steps > 0:
         print(d["final_energy"])

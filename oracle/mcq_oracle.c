@@ -112,15 +112,29 @@ typedef struct {
     uint32_t key; /* philox: the chain's seed */
     uint64_t w;   /* philox: index of the next word */
     uint32_t buf[4];
+    uint64_t words; /* words drawn so far (mcq_outputs.stream_words) */
 } rng_t;
 
 static void rng_seed(rng_t* s, int kind, uint32_t seed) {
     s->kind = kind;
+    s->words = 0;
     if (kind == MCQ_RNG_PHILOX4X32_10) s->key = seed, s->w = 0;
     else mt_seed(&s->mt, seed);
 }
 
+/* the stream chain r runs on: seeded (np.random.seed(seed), experiments.py:200-201, 287-288) or, with mcq_params.stream_states, the caller's
+ * MT19937 state continued where it stands (seed=None: the reference skips the seeding and draws from NumPy's global RandomState) */
+static void rng_start(rng_t* s, const mcq_params* p, const uint32_t* seeds, int64_t r) {
+    rng_seed(s, p->rng, seeds[r]);
+    if (p->stream_states) {
+        const uint32_t* st = p->stream_states + (size_t)r * 625;
+        memcpy(s->mt.key, st, 624 * sizeof(uint32_t));
+        s->mt.pos = (int)st[624];
+    }
+}
+
 static uint32_t rng_u32(rng_t* s) {
+    s->words++;
     if (s->kind != MCQ_RNG_PHILOX4X32_10) return mt_u32(&s->mt);
     if ((s->w & 3) == 0) {
         const uint64_t blk = s->w >> 2;
@@ -325,7 +339,7 @@ static int run_board_chain(const job_t* jb, int64_t r) {
     if (!h) return MCQ_ENOMEM;
 
     rng_t rng;
-    rng_seed(&rng, p->rng, jb->seeds[r]); /* experiments.py:287-288 */
+    rng_start(&rng, p, jb->seeds, r); /* experiments.py:287-288 */
     if (board_init(N, p->init, &rng, h) != 0) {
         free(h);
         return MCQ_EINVAL;
@@ -385,6 +399,7 @@ static int run_board_chain(const job_t* jb, int64_t r) {
     if (o->final_energy) o->final_energy[r] = E;
     if (o->steps_to_best) o->steps_to_best[r] = best_step;
     if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->stream_words) o->stream_words[r] = p->rng == MCQ_RNG_MT19937_NUMPY ? (uint32_t)rng.words : 0u;
     if (o->near_ties) o->near_ties[r] = ties;
     if (o->best_state)
         for (int c = 0; c < Q; c++) o->best_state[r * Q + c] = (uint8_t)best_h[c];
@@ -508,7 +523,7 @@ static int run_full_chain(const job_t* jb, int64_t r) {
     cell_t* best_q = q + Q;
 
     rng_t rng;
-    rng_seed(&rng, p->rng, jb->seeds[r]); /* experiments.py:200-201 */
+    rng_start(&rng, p, jb->seeds, r); /* experiments.py:200-201 */
     if (full_init(N, Q, p->init, &rng, q, occ) != 0) {
         free(q);
         free(occ);
@@ -562,6 +577,7 @@ static int run_full_chain(const job_t* jb, int64_t r) {
     if (o->final_energy) o->final_energy[r] = E;
     if (o->steps_to_best) o->steps_to_best[r] = best_step;
     if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->stream_words) o->stream_words[r] = p->rng == MCQ_RNG_MT19937_NUMPY ? (uint32_t)rng.words : 0u;
     if (o->near_ties) o->near_ties[r] = ties;
     for (int c = 0; c < Q; c++) {
         if (o->best_state) {
@@ -659,7 +675,7 @@ static int run_board_chain_fast(const job_t* jb, int64_t r) {
     }
     int* best_h = h + Q;
     rng_t rng;
-    rng_seed(&rng, p->rng, jb->seeds[r]);
+    rng_start(&rng, p, jb->seeds, r);
     if (board_init(N, p->init, &rng, h) != 0) {
         free(h), free(cnt);
         return MCQ_EINVAL;
@@ -719,6 +735,7 @@ static int run_board_chain_fast(const job_t* jb, int64_t r) {
     if (o->final_energy) o->final_energy[r] = E;
     if (o->steps_to_best) o->steps_to_best[r] = best_step;
     if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->stream_words) o->stream_words[r] = p->rng == MCQ_RNG_MT19937_NUMPY ? (uint32_t)rng.words : 0u;
     if (o->near_ties) o->near_ties[r] = ties;
     if (o->best_state)
         for (int c = 0; c < Q; c++) o->best_state[r * Q + c] = (uint8_t)best_h[c];
@@ -741,7 +758,7 @@ static int run_full_chain_fast(const job_t* jb, int64_t r) {
     }
     cell_t* best_q = q + Q;
     rng_t rng;
-    rng_seed(&rng, p->rng, jb->seeds[r]);
+    rng_start(&rng, p, jb->seeds, r);
     if (full_init(N, Q, p->init, &rng, q, occ) != 0) {
         free(q), free(occ), free(cnt);
         return MCQ_EINVAL;
@@ -796,6 +813,7 @@ static int run_full_chain_fast(const job_t* jb, int64_t r) {
     if (o->final_energy) o->final_energy[r] = E;
     if (o->steps_to_best) o->steps_to_best[r] = best_step;
     if (o->n_accepted) o->n_accepted[r] = accepted;
+    if (o->stream_words) o->stream_words[r] = p->rng == MCQ_RNG_MT19937_NUMPY ? (uint32_t)rng.words : 0u;
     if (o->near_ties) o->near_ties[r] = ties;
     for (int c = 0; c < Q; c++) {
         if (o->best_state) {
@@ -846,7 +864,7 @@ static int xchain_init(xchain_t* c, const mcq_params* p, const mcq_outputs* o, c
     memset(c, 0, sizeof *c);
     c->p = p, c->o = o, c->r = r, c->fast = fast, c->N = p->N, c->Q = queens_of(p), c->rung = rung;
     const int N = c->N, Q = c->Q;
-    rng_seed(&c->rng, p->rng, seeds[r]);
+    rng_start(&c->rng, p, seeds, r);
     if (fast) {
         c->cnt = (uint8_t*)malloc(lines_total(N));
         if (!c->cnt) return MCQ_ENOMEM;
@@ -954,6 +972,7 @@ static void xchain_finish(xchain_t* c) {
     if (o->final_energy) o->final_energy[r] = c->E;
     if (o->steps_to_best) o->steps_to_best[r] = c->best_step;
     if (o->n_accepted) o->n_accepted[r] = c->accepted;
+    if (o->stream_words) o->stream_words[r] = c->p->rng == MCQ_RNG_MT19937_NUMPY ? (uint32_t)c->rng.words : 0u;
     if (o->near_ties) o->near_ties[r] = c->ties;
     if (o->exchange_rung) o->exchange_rung[r] = c->rung;
     if (o->n_exchanges) o->n_exchanges[r] = c->n_exch;

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import mcq_amd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,6 +87,34 @@ def test_full_3d_beyond_32_sizing_and_limits():
     mcq_amd.abi.set_exchange(p, 10, [1.0, 0.8, 0.6, 0.4])
     assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and b"without replica exchange" in L.mcq_last_error()
     assert L.mcq_default_lanes_n(1, 40) == 16 and L.mcq_default_lanes_n(1, 32) == 8
+
+
+def test_stream_layout_rewinds_the_unconsumed_generation():
+    """mcq_params.stream_states: NumPy holds the 624 words of the CURRENT generation, the kernels twist a generation block by block as its words are
+    needed.  The library therefore rewinds the words behind the (rounded-up) position to the generation before; twisting them again -- what the
+    kernels will do -- must give NumPy's words back, for every position class."""
+    L = mcq_amd._lib.lib()
+    rs = np.random.RandomState(77)
+    UP, LO, A = 0x80000000, 0x7FFFFFFF, 0x9908B0DF
+    for pos in (0, 1, 15, 16, 63, 64, 65, 226, 227, 228, 300, 396, 397, 398, 575, 576, 577, 608, 623, 624):
+        rs.randint(0, 2**32, size=1000, dtype=np.uint32)
+        key = np.array(rs.get_state()[1], dtype=np.uint32)
+        st = np.concatenate([key, np.array([pos], dtype=np.uint32)])
+        out = np.zeros(626, dtype=np.uint32)
+        L.mcq_stream_layout(st.ctypes.data, out.ctypes.data)
+        if pos == 624:  # the key IS the generation before the one the next draw starts
+            assert out[624] == 0 and out[625] == 0 and (out[:624] == key).all()
+            continue
+        ge = min(624, (pos + 63) & ~63)
+        assert out[624] == pos and out[625] == ge and (out[:ge] == key[:ge]).all()
+        w = [int(x) for x in out[:624]]
+        for i in range(ge, 624):  # the twist, word by word and in place, as the kernels run it
+            y = (w[i] & UP) | (w[(i + 1) % 624] & LO)
+            w[i] = w[(i + 397) % 624] ^ (y >> 1) ^ (A if y & 1 else 0)
+        assert w == [int(x) for x in key], pos
+    p = mcq_amd.abi.make_params(6, 10, "random", {"type": "constant", "beta_const": 1.0}, 2, mcmc_type="board", rng="philox")
+    mcq_amd.abi.set_stream_states(p, [np.random.RandomState(1).get_state()] * 2)
+    assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and b"continues an MT19937 stream" in L.mcq_last_error()
 
 
 def test_n_chains_bound_and_diag_gate():

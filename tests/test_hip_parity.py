@@ -104,6 +104,86 @@ def test_golden_full_3d_beyond_32(golden):
             mcq_amd._lib.run_host(abi.make_params(33, 10, "random", sp, 4, mcmc_type="full_3d", **kw), abi.seeds_for(1, 4))
 
 
+def test_golden_chains_that_continue_a_stream(golden):
+    """metropolis_mcmc[_board](..., seed=None) (experiments.py:200-201, 287-288): the reference's chains started from NumPy states at every position
+    class, at every lane width; mcq_outputs.stream_words must put the caller's stream where the reference left the global one.  Then against the
+    oracle: many chains with positions of their own, sets with different inits, early stops, the reduced trace, replica exchange."""
+    for case in golden.chains_stream:
+        state, after = golden.stream_state(case)
+        wide = case["mode"] == "full_3d" and case["N"] > 32
+        for lanes in ((0, 16) if wide else (0, 8, 16) if case["N"] > 32 else (0, 2, 4, 8, 16) if case["mode"] == "board" else (0, 4, 8, 16)):
+            p = abi.set_stream_states(util.params_for_case(case, lanes_per_chain=lanes), state[None, :])
+            res, _ = mcq_amd._lib.run_host(p, np.array([0], dtype=np.uint32))
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"hip G={lanes} vs reference {case}")
+            np.testing.assert_array_equal(util.words_after(state, res["stream_words"][0]), after, err_msg=f"G={lanes}: stream position after {case}")
+    sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}
+    rs = np.random.RandomState(4321)
+
+    def states(n):
+        out = np.zeros((n, 625), dtype=np.uint32)
+        for r in range(n):
+            rs.randint(0, 2**32, size=int(rs.randint(1, 2000)), dtype=np.uint32)
+            out[r, :624] = rs.get_state()[1]
+            out[r, 624] = rs.choice([0, 1, 63, 64, 65, 300, 575, 576, 577, 623, 624, int(rs.randint(0, 625))])
+        return out
+
+    for N, mode, init, n, patience, trace in ((12, "board", "random", 150, None, True), (12, "full_3d", "random", 70, None, True), (24, "board", "klarner", 40, 60, True),
+                                              (7, "board", "latin", 33, None, "reduced"), (20, "full_3d", "klarner", 9, None, False), (40, "full_3d", "random", 5, None, True),
+                                              (3, "board", "random", 64, 25, True), (17, "board", "random", 19, None, True)):
+        p = abi.set_stream_states(abi.make_params(N, 900, init, sp, n, mcmc_type=mode, early_stop_patience=patience), states(n))
+        seeds = np.zeros(n, dtype=np.uint32)
+        want = oracle.run(p, seeds, fast=True, n_threads=8)
+        got, _ = mcq_amd._lib.run_host(p, seeds, trace=trace)
+        util.assert_results_equal(got, want, f"continued streams: N={N} {mode} {init}", trace=trace is True)
+        assert (got["stream_words"] > 0).all()
+    scheds = [sp, {"type": "constant", "beta_const": 2.0}, {"type": "sinusoidal_annealing", "beta_start": 0.1, "beta_end": 5.0}]
+    p = abi.set_stream_states(abi.make_params_sets(9, 700, "random", scheds, 16, mcmc_type="board", init_modes=["klarner", "random", "latin"]), states(48))
+    want = oracle.run(p, np.zeros(48, dtype=np.uint32), n_threads=8)
+    got, _ = mcq_amd._lib.run_host(p, np.zeros(48, dtype=np.uint32))
+    util.assert_results_equal(got, want, "continued streams: three sets")
+    p = abi.set_stream_states(abi.make_params(12, 2000, "random", sp, 32, mcmc_type="board", early_stop_patience=None), states(32))
+    abi.set_exchange(p, 10, [1.0, 0.8, 0.6, 0.45])
+    want = oracle.run(p, np.zeros(32, dtype=np.uint32), n_threads=8)
+    got, _ = mcq_amd._lib.run_host(p, np.zeros(32, dtype=np.uint32))
+    util.assert_results_equal(got, want, "continued streams: replica exchange")
+    # a seeded run reports its words too, and they equal the oracle's (RESULT_FIELDS): here against NumPy itself for one chain
+    p = abi.make_params(6, 200, "random", sp, 1, mcmc_type="board")
+    got, _ = mcq_amd._lib.run_host(p, np.array([99], dtype=np.uint32))
+    st = np.random.RandomState(99).get_state()
+    q = abi.set_stream_states(abi.make_params(6, 200, "random", sp, 1, mcmc_type="board"), st)
+    again, _ = mcq_amd._lib.run_host(q, np.array([0], dtype=np.uint32))
+    util.assert_results_equal(again, got, "seeded == continued from the seeded state")
+
+
+def test_seed_none_through_the_python_api(golden):
+    """The drop-in call without a seed (the reference's default): metropolis_mcmc[_board] draw from np.random's global stream and leave it where
+    the reference leaves it -- the chain's dict equals the reference's and so do the next words of the global stream; two calls in a row continue
+    each other (the second equals a chain started from the state the first left)."""
+    ex = mcq_amd.experiments
+    for case in golden.chains_stream[::3]:
+        state, after = golden.stream_state(case)
+        gold = golden.chain(case)
+        np.random.set_state(("MT19937", state[:624], int(state[624])))
+        sched = ex.build_schedule_from_params(case["schedule"]["type"], case["n_steps"], case["schedule"].get("beta_const"),
+                                              case["schedule"].get("beta_start"), case["schedule"].get("beta_end"))
+        fn = ex.metropolis_mcmc_board if case["mode"] == "board" else ex.metropolis_mcmc
+        d = fn(case["N"], case["n_steps"], case["init"], sched, verbose=False, schedule_params=case["schedule"])  # no seed
+        np.testing.assert_array_equal(np.random.randint(0, 2**32, size=4, dtype=np.uint32), after, err_msg=f"global stream after {case}")
+        np.testing.assert_array_equal(d["energy_history"], gold["hist"], err_msg=str(case))
+        assert d["best_energy"] == int(gold["best_energy"]) and d["final_energy"] == int(gold["final_energy"]) and d["steps_to_best"] == int(gold["steps_to_best"])
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    sched = ex.build_schedule_from_params("linear_annealing", 400, None, 1.0, 3.0)
+    np.random.seed(2024)
+    first = ex.metropolis_mcmc_board(7, 400, "random", sched, verbose=False, schedule_params=sp)
+    mid = np.random.get_state()
+    second = ex.metropolis_mcmc_board(7, 400, "random", sched, verbose=False, schedule_params=sp)
+    p = abi.set_stream_states(abi.make_params(7, 400, "random", sp, 1, mcmc_type="board", early_stop_patience=None), mid)
+    want = oracle.run(p, np.zeros(1, dtype=np.uint32))
+    np.testing.assert_array_equal(second["energy_history"], want["energy_hist"][0, : int(want["hist_len"][0])])
+    seeded = ex.metropolis_mcmc_board(7, 400, "random", sched, verbose=False, seed=2024, schedule_params=sp)
+    np.testing.assert_array_equal(first["energy_history"], seeded["energy_history"])  # np.random.seed(s) then seed=None == seed=s
+
+
 def test_queen_counts_against_the_oracle():
     """Q != N^2 at sizes the golden chains do not reach: many chains per launch, reduced trace, Philox, sets."""
     sp = {"type": "linear_annealing", "beta_start": 0.5, "beta_end": 3.0}

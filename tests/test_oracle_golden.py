@@ -63,6 +63,29 @@ def test_golden_full_3d_beyond_32(golden):
             util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
 
 
+def test_golden_chains_that_continue_a_stream(golden):
+    """metropolis_mcmc[_board](..., seed=None) skips np.random.seed and draws from the global stream where it stands (experiments.py:200-201,
+    287-288): 36 reference chains started from states at every position class (0, inside a generation, block edges, 624), and the words the
+    global stream yields AFTER each chain -- which pins mcq_outputs.stream_words, the count a caller advances its own stream by."""
+    assert len(golden.chains_stream) >= 36
+    for case in golden.chains_stream:
+        state, after = golden.stream_state(case)
+        p = abi.set_stream_states(util.params_for_case(case), state[None, :])
+        for fast in (False, True):
+            res = oracle.run(p, np.array([0], dtype=np.uint32), fast=fast)
+            util.assert_chain_equals_golden(res, 0, case, golden.chain(case), f"oracle (fast={fast}) vs reference {case}")
+            np.testing.assert_array_equal(util.words_after(state, res["stream_words"][0]), after, err_msg=f"stream position after {case}")
+    # a seeded chain is the same chain as one continued from the freshly seeded state
+    sp = {"type": "linear_annealing", "beta_start": 1.0, "beta_end": 3.0}
+    p = abi.make_params(8, 300, "random", sp, 3, mcmc_type="board")
+    seeds = np.array([5, 6, 7], dtype=np.uint32)
+    want = oracle.run(p, seeds)
+    q = abi.set_stream_states(abi.make_params(8, 300, "random", sp, 3, mcmc_type="board"), [np.random.RandomState(int(s)).get_state() for s in seeds])
+    got = oracle.run(q, np.zeros(3, dtype=np.uint32))
+    util.assert_results_equal(got, want, "seeded == continued from the seeded state")
+    assert (want["stream_words"] > 300 * 5).all()
+
+
 def test_queen_count_errors():
     """Where the reference raises (mcmc.py:21-25, 94-95) and where this build's limits are."""
     sp = {"type": "constant", "beta_const": 1.0}

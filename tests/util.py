@@ -42,9 +42,20 @@ class Golden:
         """full_3d chains beyond N = 32 (the reference is unbounded, mcmc.py:6-18)"""
         return self.manifest["chains_wide"]
 
+    @property
+    def chains_stream(self):
+        """chains that continue NumPy's global stream (metropolis_mcmc[_board](..., seed=None), experiments.py:200-201, 287-288)"""
+        return self.manifest["chains_stream"]
+
+    def stream_state(self, case):
+        """(uint32[625] key words + position the chain started from, the four words the global stream yields after the chain)"""
+        z = self.npz("chains_stream")
+        return z[f"{case['key']}_state"], z[f"{case['key']}_after"]
+
     def chain(self, case):
         key = case["key"]
-        z = self.npz("chains_q" if key.startswith("q") else "chains_big" if key.startswith("big") else "chains_wide" if key.startswith("wide") else "chains")
+        z = self.npz("chains_q" if key.startswith("q") else "chains_big" if key.startswith("big") else "chains_wide" if key.startswith("wide") else
+                     "chains_stream" if key.startswith("stream") else "chains")
         return {k: z[f"{case['key']}_{k}"] for k in
                 ("hist", "accept", "n_executed", "best_energy", "final_energy", "steps_to_best", "best_state", "final_state")}
 
@@ -52,6 +63,18 @@ class Golden:
 def params_for_case(case, n_chains=1, **kw):
     return abi.make_params(case["N"], case["n_steps"], case["init"], case["schedule"], n_chains,
                            mcmc_type=case["mode"], early_stop_patience=case.get("patience"), Q=case.get("Q"), **kw)
+
+
+def words_after(state625, n_words, count=4):
+    """The `count` 32-bit words an MT19937 stream yields after `n_words` more have been taken from the given state (NumPy itself does the walking)."""
+    rs = np.random.RandomState()
+    rs.set_state(("MT19937", np.asarray(state625[:624], dtype=np.uint32), int(state625[624])))
+    left = int(n_words)
+    while left > 0:
+        step = min(left, 1 << 22)
+        rs.randint(0, 2**32, size=step, dtype=np.uint32)
+        left -= step
+    return rs.randint(0, 2**32, size=count, dtype=np.uint32)
 
 
 def accept_bytes(bits_row, n_steps):
@@ -78,7 +101,7 @@ def assert_chain_equals_golden(res, r, case, gold, what):
 
 
 RESULT_FIELDS = ("hist_len", "steps_executed", "initial_energy", "best_energy", "final_energy", "steps_to_best",
-                 "n_accepted", "best_state", "final_state")
+                 "n_accepted", "best_state", "final_state", "stream_words")
 
 
 def assert_results_equal(a, b, what, trace=True):

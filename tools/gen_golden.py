@@ -224,6 +224,38 @@ def wide_cases():
     return cases
 
 
+def stream_cases():
+    """Chains that continue NumPy's global stream instead of seeding it (metropolis_mcmc[_board](..., seed=None), experiments.py:200-201,
+    287-288): the state the chain starts from (key words + position, every position class: 0, inside a generation, 624), the chain's
+    results, and the four 32-bit words the global stream yields AFTER the chain.  chains_stream.npz / manifest["chains_stream"],
+    `python tools/gen_golden.py --only stream`."""
+    cases = []
+    shapes = [("board", "random", 6, 300), ("board", "latin", 12, 400), ("board", "klarner", 9, 300), ("full_3d", "random", 6, 300),
+              ("full_3d", "latin", 12, 300), ("full_3d", "klarner", 10, 200), ("board", "random", 33, 120), ("full_3d", "random", 33, 100)]
+    positions = [0, 1, 15, 16, 63, 64, 65, 300, 576, 608, 609, 623, 624]
+    for idx, (mode, init, N, n_steps) in enumerate(shapes):
+        for pos in (positions[idx::3] if idx else positions):
+            cases.append({"mode": mode, "init": init, "schedule": SCHEDULES[1], "N": N, "seed": 1000 + idx, "n_steps": n_steps, "stream_pos": pos,
+                          "warm_words": 624 * (idx % 3) + 7})
+    for idx, c in enumerate(cases):
+        c["key"] = f"stream{idx:03d}"
+    return cases
+
+
+def run_stream_chain(job):
+    """np.random.seed(case seed); draw warm_words words; force the position; run the chain with seed=None."""
+    ref_path, case = job
+    np.random.seed(case["seed"])
+    np.random.randint(0, 2**32, size=case["warm_words"], dtype=np.uint32)
+    st = np.random.get_state()
+    key = np.array(st[1], dtype=np.uint32)
+    np.random.set_state(("MT19937", key, case["stream_pos"]))
+    res = run_chain((ref_path, dict(case, seed=None)))
+    res["state"] = np.concatenate([key, np.array([case["stream_pos"]], dtype=np.uint32)])
+    res["after"] = np.random.randint(0, 2**32, size=4, dtype=np.uint32)
+    return res
+
+
 def gen_beta(ref_path, out):
     """F5: float64 beta(step) tables of the five schedule closures."""
     ex = _ref(ref_path)
@@ -320,14 +352,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--workers", type=int, default=8)
-    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz); 'big': only the boards beyond N = 32 (chains_big.npz); 'wide': only the full_3d chains beyond N = 32 (chains_wide.npz); merged into the existing manifest")
+    ap.add_argument("--only", default="", help="'q': only the Q != N^2 chains (chains_q.npz); 'big': only the boards beyond N = 32 (chains_big.npz); 'wide': only the full_3d chains beyond N = 32 (chains_wide.npz); 'stream': only the seed=None chains (chains_stream.npz); merged into the existing manifest")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    if args.only in ("q", "big", "wide"):
+    if args.only in ("q", "big", "wide", "stream"):
         name = "chains_" + args.only
-        cases = {"q": q_cases, "big": big_cases, "wide": wide_cases}[args.only]()
+        cases = {"q": q_cases, "big": big_cases, "wide": wide_cases, "stream": stream_cases}[args.only]()
         with ProcessPoolExecutor(max_workers=args.workers) as pool:
-            results = list(pool.map(run_chain, [(args.reference, c) for c in cases], chunksize=2))
+            results = list(pool.map(run_stream_chain if args.only == "stream" else run_chain, [(args.reference, c) for c in cases], chunksize=2))
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **{f"{c['key']}_{k}": v for c, r in zip(cases, results) for k, v in r.items()})
         with open(os.path.join(OUT, "manifest.json")) as f:
             manifest = json.load(f)
