@@ -232,7 +232,8 @@ class DeviceRun:
     torch is used only as the allocator / stream provider; the kernels are launched by
     libmcq_hip.so through raw device pointers."""
 
-    def __init__(self, params, seeds, trace=True, states=True, device=None):
+    def __init__(self, params, seeds, trace=True, states=True, device=None, stream_words=True):
+        """stream_words=False leaves mcq_outputs.stream_words NULL (a job list has no use for it: one small kernel less per launch)."""
         import torch
 
         self.torch = torch
@@ -245,6 +246,8 @@ class DeviceRun:
         self.out = abi.Outputs()
         with torch.cuda.device(self.device):
             for k, shape in abi.output_shapes(self.p, trace=trace, states=states).items():
+                if k == "stream_words" and not stream_words:
+                    continue
                 self.t[k] = torch.empty(shape, dtype=tdt[abi.OUTPUT_DTYPES[k]], device=self.device)
                 setattr(self.out, k, self.t[k].data_ptr())
             s = np.ascontiguousarray(seeds, dtype=np.uint32)
