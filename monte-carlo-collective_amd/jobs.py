@@ -212,7 +212,7 @@ class JobSet:
                 p = abi.make_params(j0["N"], j0["n_steps"], j0["init_mode"], j0["schedule_params"], n, mcmc_type=j0["mcmc_type"],
                                     early_stop_patience=j0["early_stop_patience"], trace=self.trace, lanes_per_chain=lanes_per_chain, rng=rng)
                 seeds = self.shards[ids[0]][0]
-            run = _lib.DeviceRun(p, seeds, trace=self.trace, states=False, stream_words=False)
+            run = _lib.DeviceRun(p, seeds, trace=self.trace, states=False, stream_words=os.environ.get("MCQ_JOB_STREAM_WORDS") == "1")  # (experiment hook: the count costs a job list one small kernel per launch)
             la = _Launch(ids, run, n, n)
             self.launches.append(la)  # (its stream: below, once it is known whether the launches get CUs of their own)
         # longest first, by the estimated time of one of its wavefronts: the launches that follow fill in behind it
