@@ -1105,6 +1105,11 @@ static int oracle_run_impl(const mcq_params* p, const uint32_t* seeds, const mcq
     if (p->abi_version != MCQ_ABI_VERSION) return fail(MCQ_EINVAL, "abi_version mismatch");
     if (p->N < MCQ_MIN_N || p->N > (p->mode == MCQ_MODE_BOARD ? MCQ_MAX_N_BOARD : MCQ_MAX_N)) return fail(MCQ_EINVAL, "N out of range");
     if (p->mode != MCQ_MODE_BOARD && p->mode != MCQ_MODE_FULL3D) return fail(MCQ_EINVAL, "unknown mcmc_type");
+    if (p->stream_states) {
+        if (p->rng != MCQ_RNG_MT19937_NUMPY) return fail(MCQ_EINVAL, "stream_states continues an MT19937 stream (a Philox stream is a function of its seed)");
+        for (int64_t r = 0; r < p->n_chains; r++)
+            if (p->stream_states[r * 625 + 624] > 624u) return fail(MCQ_EINVAL, "stream_states: MT19937 position out of range");
+    }
     if (p->init < MCQ_INIT_RANDOM || p->init > MCQ_INIT_KLARNER) return fail(MCQ_EINVAL, "Unknown init_mode");
     if (p->sched < MCQ_SCHED_CONSTANT || p->sched > MCQ_SCHED_SINUSOIDAL)
         return fail(MCQ_EINVAL, "Unknown betta_scheduling type");

@@ -115,6 +115,11 @@ def test_stream_layout_rewinds_the_unconsumed_generation():
     p = mcq_amd.abi.make_params(6, 10, "random", {"type": "constant", "beta_const": 1.0}, 2, mcmc_type="board", rng="philox")
     mcq_amd.abi.set_stream_states(p, [np.random.RandomState(1).get_state()] * 2)
     assert L.mcq_workspace_bytes(ctypes.byref(p)) == 0 and b"continues an MT19937 stream" in L.mcq_last_error()
+    from oracle import oracle
+
+    import pytest
+    with pytest.raises(ValueError, match="continues an MT19937 stream"):  # the oracle refuses the same
+        oracle.run(p, np.zeros(2, dtype=np.uint32))
 
 
 def test_n_chains_bound_and_diag_gate():
