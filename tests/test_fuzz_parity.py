@@ -272,3 +272,56 @@ def test_random_full_3d_beyond_32():
             got, _ = mcq_amd._lib.run_host(p, seeds, trace=k["trace"])
             util.assert_results_equal(got, want, what, trace=bool(k["trace"]))
         assert got["near_ties"].sum() == 0, what
+
+
+def _stream_cases(n=int(os.environ.get("MCQ_FUZZ_STREAM_CASES", "60"))):
+    rng = np.random.default_rng(FUZZ_SEED + 6)
+    scheds = ["constant", "linear_annealing", "exponential_annealing", "logarithmic_annealing", "sinusoidal_annealing"]
+    out = []
+    for c in range(n):
+        st = str(rng.choice(scheds))
+        sp = {"type": st, "beta_const": float(rng.choice([0.0, 0.3, 1.0, 2.5]))} if st == "constant" else \
+            {"type": st, "beta_start": float(rng.choice([0.1, 0.5, 1.0])), "beta_end": float(rng.choice([2.0, 3.0, 6.0]))}
+        mode = "board" if rng.random() < 0.55 else "full_3d"
+        N = int(rng.choice([2, 3, 5, 8, 9, 12, 13, 16, 17, 24, 33, 40])) if mode == "board" else int(rng.choice([2, 3, 6, 9, 10, 12, 13, 16, 20, 33, 41]))
+        wide = mode == "full_3d" and N > 32
+        lanes = int(rng.choice([0, 16])) if wide else int(rng.choice([0, 8, 16])) if N > 32 else int(rng.choice([0, 2, 4, 8, 16] if mode == "board" else [0, 4, 8, 16]))
+        n_chains = int(rng.choice([1, 3, 16, 17, 33]))
+        if lanes == 2 and n_chains > 1:
+            n_chains = int(rng.choice([31, 32, 33, 64]))
+        k = dict(c=c, N=N, mode=mode, sp=sp, lanes=lanes, n_chains=n_chains, init=str(rng.choice(["random", "latin", "klarner"])),
+                 n_steps=int(rng.choice([0, 1, 16, 17, 100, 300, 700])) if not FUZZ_LONG else int(rng.choice([1500, 4000])),
+                 patience=int(rng.choice([0, 3, 25, 120])) if mode == "board" and rng.random() < 0.3 else None,
+                 trace=[True, False, "reduced"][int(rng.integers(0, 3))], seed0=int(rng.integers(0, 2**31)))
+        out.append(k)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_random_continued_streams():
+    """Chains that continue MT19937 states (mcq_params.stream_states; the reference's seed=None) at random: states at random positions of random
+    generations -- the block edges 0 / 64k / 624 among them --, both modes, every lane width, early stops, every trace mode; results AND the words
+    taken from the stream (stream_words) against the oracle."""
+    for k in _stream_cases():
+        what = str(k)
+        rs = np.random.RandomState(k["seed0"] % (2**32))
+        states = np.zeros((k["n_chains"], 625), dtype=np.uint32)
+        for r in range(k["n_chains"]):
+            rs.randint(0, 2**32, size=int(rs.randint(1, 1500)), dtype=np.uint32)
+            states[r, :624] = rs.get_state()[1]
+            states[r, 624] = rs.choice([0, 64, 128, 576, 623, 624, int(rs.randint(0, 625)), int(rs.randint(0, 625))])
+        p = abi.set_stream_states(abi.make_params(k["N"], k["n_steps"], k["init"], k["sp"], k["n_chains"], mcmc_type=k["mode"], early_stop_patience=k["patience"],
+                                                  lanes_per_chain=k["lanes"], trace=k["trace"]), states)
+        seeds = np.zeros(k["n_chains"], dtype=np.uint32)
+        want = oracle.run(p, seeds, n_threads=8, fast=bool(k["c"] & 1))
+        if k["trace"] == "reduced":
+            got, _ = mcq_amd._lib.run_host(p, seeds, trace="reduced")
+            util.assert_results_equal(got, want, what, trace=False)
+            st = mcq_amd.jobs.stats_from_trace(want, k["n_steps"])
+            for f in ("step_sum", "step_sumsq", "step_accepted", "step_count"):
+                np.testing.assert_array_equal(got[f], st[f], err_msg=f"{what}: {f}")
+        else:
+            got, _ = mcq_amd._lib.run_host(p, seeds, trace=k["trace"])
+            util.assert_results_equal(got, want, what, trace=bool(k["trace"]))
+        assert got["near_ties"].sum() == 0, what
