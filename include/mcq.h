@@ -86,7 +86,7 @@ extern "C" {
 /* Upper bounds of this build (N >= 2 is required by the reference loop at experiments.py:317-319; the reference itself is
  * unbounded).  full_3d: column occupancy is one word per column -- 16 bits up to N = 16, 32 up to N = 32, 64 up to N = 64 (that variant:
  * 16 lanes per chain, NumPy's stream, no replica exchange; the queen table and the N^3 cells np.random.choice permutes live in the
- * workspace: N^3 * 4 bytes for each of at most 256 chains at a time).  board: bit masks up to N = 32, a compare per probed
+ * workspace: N^3 * 4 bytes for each of the chains one round of the init kernel takes -- as many as 1 GiB holds).  board: bit masks up to N = 32, a compare per probed
  * height beyond (slower, any size whose N*N heights fit a wavefront's share of the LDS and whose accept flags fit a byte). */
 #define MCQ_MIN_N 2
 #define MCQ_MAX_N 64        /* mcmc_type full_3d (beyond 32: 64-bit column words, 16 lanes per chain) */

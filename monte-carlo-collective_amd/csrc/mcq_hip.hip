@@ -2315,8 +2315,10 @@ int rec_words_for(const mcq_params* p) { return (REC_STATE + (int)((state_bytes_
 // full_3d: entries per chain of the packed queen table in the workspace (64-byte rows; uint16 entries, uint32 beyond N = 32); 0 for boards
 int qtab_stride_for(const mcq_params* p) { return p->mode == MCQ_MODE_FULL3D ? (queens_of(p) + 31) & ~31 : 0; }
 size_t qtab_bytes_for(const mcq_params* p) { return (size_t)(p->n_chains > 0 ? p->n_chains : 1) * (size_t)qtab_stride_for(p) * (p->N > 32 ? 4 : 2); }
-// full_3d beyond N = 32 with a random init: the init kernel's permutation arrays (N^3 uint32 per chain) for PERM_SLOTS chains at a time
-constexpr long long PERM_SLOTS = 256;
+// full_3d beyond N = 32 with a random init: the init kernel's permutation arrays (N^3 uint32 per chain) for as many chains at a time as 1 GiB holds
+// (N = 33: 7 468, N = 64: 1 024) -- one chain per wavefront, so a round should bring a wavefront for every SIMD -- and never fewer than 256
+constexpr long long PERM_SLOTS_MIN = 256;
+constexpr long long PERM_BUDGET_BYTES = 1LL << 30;
 bool any_random_init(const mcq_params* p) {
     bool any = p->init == MCQ_INIT_RANDOM;
     for (int64_t t = 0; t < p->n_sets && p->n_sets > 1; t++) any |= p->sets[t].init_plus1 == MCQ_INIT_RANDOM + 1;
@@ -2324,7 +2326,8 @@ bool any_random_init(const mcq_params* p) {
 }
 long long perm_slots_for(const mcq_params* p) {
     if (p->mode != MCQ_MODE_FULL3D || p->N <= 32 || !any_random_init(p)) return 0;
-    return p->n_chains < PERM_SLOTS ? ((p->n_chains > 0 ? p->n_chains : 1) + 3) & ~3LL : PERM_SLOTS;  // (a multiple of the init kernel's chains per wavefront)
+    const long long per_chain = (long long)p->N * p->N * p->N * 4, fit = (PERM_BUDGET_BYTES / per_chain) & ~3LL, cap = fit > PERM_SLOTS_MIN ? fit : PERM_SLOTS_MIN;
+    return p->n_chains < cap ? ((p->n_chains > 0 ? p->n_chains : 1) + 3) & ~3LL : cap;  // (a multiple of the init kernel's chains per wavefront)
 }
 size_t perm_bytes_for(const mcq_params* p) { return (size_t)perm_slots_for(p) * (size_t)p->N * p->N * p->N * 4; }
 // mcq_params.stream_states in the kernels' layout: 626 words per chain (stream_layout), behind everything else in the workspace

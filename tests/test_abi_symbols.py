@@ -67,13 +67,13 @@ def test_pure_helpers_without_gpu():
 
 def test_full_3d_beyond_32_sizing_and_limits():
     """full_3d at N = 33..64 (64-bit column words): the workspace holds the queen table as 32-bit entries and, for a random init, the
-    N^3 cells np.random.choice permutes for at most 256 chains at a time; what the variant does not run is an explicit error."""
+    N^3 cells np.random.choice permutes for as many chains at a time as 1 GiB holds; what the variant does not run is an explicit error."""
     L = mcq_amd._lib.lib()
     sp = {"type": "constant", "beta_const": 1.0}
     make = mcq_amd.abi.make_params
     fixed = 8192 + 4096 + 2048 * 16 * 4 + 128  # tables of 1000 steps, pacing rows, exchange ladder
     rec = lambda Q: ((628 + (3 * Q + 3) // 4 + 15) & ~15) * 4  # noqa: E731  (chain record: MT words, cursor, E0, 3 Q state bytes; 64-byte multiple)
-    for chains, slots in ((10, 12), (1000, 256)):
+    for chains, slots in ((10, 12), (1000, 1000), (5000, 1024)):
         p = make(64, 1000, "random", sp, chains, mcmc_type="full_3d")
         assert L.mcq_workspace_bytes(ctypes.byref(p)) == fixed + chains * (rec(4096) + 4096 * 4) + slots * 64**3 * 4
         p = make(64, 1000, "latin", sp, chains, mcmc_type="full_3d")

@@ -67,7 +67,7 @@ def test_golden_boards_beyond_32(golden):
 def test_golden_full_3d_beyond_32(golden):
     """full_3d up to N = 64 (64-bit column words, 16 lanes per chain, the queens and the init kernel's N^3 permutation in global memory): the
     reference's chains at N = 33..64 (mcmc.py:6-18 is unbounded), then against the oracle: more chains than the init kernel has permutation
-    slices (its launches come one after the other), the reduced trace, sets with different inits, Q != N^2."""
+    slices (its rounds come one after the other), the reduced trace, sets with different inits, Q != N^2."""
     for case in golden.chains_wide:
         for lanes in (0, 16):
             p = util.params_for_case(case, lanes_per_chain=lanes)
@@ -82,6 +82,12 @@ def test_golden_full_3d_beyond_32(golden):
         got, _ = mcq_amd._lib.run_host(p, seeds)
         util.assert_results_equal(got, want, f"N={N} {init} Q={Q}")
         assert got["near_ties"].sum() == 0
+    # more chains than one round of the init kernel takes (N = 64: the 1 GiB of permutation slices hold 1 024 chains), no trace
+    p = abi.make_params(64, 40, "random", sp, 1030, mcmc_type="full_3d", trace=False)
+    seeds = abi.seeds_for(7, 1030)
+    want = oracle.run(p, seeds, fast=True, n_threads=8, trace=False)
+    got, _ = mcq_amd._lib.run_host(p, seeds, trace=False)
+    util.assert_results_equal(got, want, "N=64, 1030 chains: two init rounds", trace=False)
     # reduced trace
     p = abi.make_params(40, 2000, "random", sp, 21, mcmc_type="full_3d")
     seeds = abi.seeds_for(9, 21)
